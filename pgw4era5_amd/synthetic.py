@@ -1,0 +1,164 @@
+"""
+Deterministic synthetic ERA5 file + climate-delta set of the shape step_03 touches
+(SURVEY.md section 8d / appendix B).  Used by bench.py, the tests and smoke(); there is no
+network and the reference ships no sample data (.gitignore:11-12 of the reference excludes
+*.nc), so every run is on these arrays.
+
+The hybrid coefficients are a generated monotone set, NOT ECMWF's L137 table (which is in
+neither the reference nor the container): ak[0] = bk[0] = 0 so that the top half level hits
+the `p > 0` guard of integ_geopot (functions.py:135), bk[N] = 1, ak[N] = 0, pure-pressure
+levels above ~70 hPa and a smooth blend below.
+"""
+import datetime as _dt
+
+import numpy as np
+
+CON_G = 9.80665
+
+# CMIP6 Amon plev19 [Pa], descending as in the files (step_01 output)
+PLEV19 = np.array([100000., 92500., 85000., 70000., 60000., 50000., 40000., 30000., 25000.,
+                   20000., 15000., 10000., 7000., 5000., 3000., 2000., 1000., 500., 100.])
+
+
+def hybrid_coefficients(nlev, p_top_first=None):
+    """Monotone synthetic hybrid half-level coefficients (ak [Pa], bk [1]), length nlev+1."""
+    n = nlev
+    k = np.arange(n + 1, dtype=np.float64)
+    # reference half-level pressures at ps = 101325: geometric from ~1 Pa (L137-like top at
+    # 0.01 hPa for the first non-zero half level) to the surface
+    p1 = 1.0 if p_top_first is None else float(p_top_first)
+    p_ref = np.empty(n + 1)
+    p_ref[0] = 0.0
+    p_ref[1:] = p1 * (101325.0 / p1) ** ((k[1:] - 1) / (n - 1))
+    # b: zero above 7000 Pa, smooth monotone blend to 1 at the surface
+    s = np.clip((p_ref - 7000.0) / (101325.0 - 7000.0), 0.0, 1.0)
+    bk = s ** 1.6
+    bk[-1] = 1.0
+    ak = p_ref - bk * 101325.0
+    ak[-1] = 0.0
+    ak[0] = 0.0
+    bk[0] = 0.0
+    return ak, bk
+
+
+def _smooth2d(rng, nlat, nlon, nmodes=6):
+    """Smooth random field in [0,1] from a few low-order harmonics (periodic in lon)."""
+    lat = np.linspace(-0.5 * np.pi, 0.5 * np.pi, nlat)[:, None]
+    lon = np.linspace(0, 2 * np.pi, nlon, endpoint=False)[None, :]
+    f = np.zeros((nlat, nlon))
+    for _ in range(nmodes):
+        kx = rng.integers(1, 5); ky = rng.integers(1, 4)
+        ph1, ph2 = rng.uniform(0, 2 * np.pi, 2)
+        f += rng.uniform(0.3, 1.0) * np.sin(kx * lon + ph1) * np.cos(ky * lat + ph2)
+    f -= f.min()
+    f /= max(f.max(), 1e-30)
+    return f
+
+
+def make_case(nlat=10, nlon=10, nlev=20, seed=0, dtype=np.float64, plev=None, nsoil=4,
+              target_dt=None, noise=True):
+    """Build one synthetic ERA5 file and the monthly deltas on the same grid.
+
+    Returns dict(era=..., deltas=..., delta_times=..., plev=..., target_dt=..., lat, lon).
+    4-D arrays are C-order (time=1, lev, lat, lon) in `dtype`; coefficients are float64.
+    """
+    rng = np.random.default_rng(seed)
+    plev = PLEV19 if plev is None else np.asarray(plev, dtype=np.float64)
+    S = len(plev)
+    dt = np.dtype(dtype)
+    ak, bk = hybrid_coefficients(nlev)
+    akm = 0.5 * (ak[1:] - ak[:-1]) + ak[:-1]
+    bkm = 0.5 * (bk[1:] - bk[:-1]) + bk[:-1]
+
+    orog = 5000.0 * _smooth2d(rng, nlat, nlon) ** 3
+    land = (_smooth2d(rng, nlat, nlon) > 0.5).astype(np.float64)
+    orog *= land                                         # sea level over ocean
+    fis = CON_G * orog
+    ps = 101325.0 * np.exp(-orog / 8000.0) * (1 + 0.01 * np.clip(rng.standard_normal((nlat, nlon)), -3, 3))
+
+    def noise4(scale, n):
+        if not noise:
+            return np.zeros((1, n, nlat, nlon), dtype=dt)
+        return (scale * rng.standard_normal((1, n, nlat, nlon), dtype=np.float32)).astype(dt, copy=False)
+
+    pa = (akm[None, :, None, None] + ps[None, None] * bkm[None, :, None, None])
+    z = -8000.0 * np.log(pa / 101325.0)
+    T = np.maximum(288.0 - 0.0065 * z, 215.0)
+    del z
+    T = (T + noise4(1.0, nlev)).astype(dt, copy=False)
+    # humidity from RH ~ U(10,95) % through the IFS formulas (functions.py:74-125)
+    rh = rng.uniform(10.0, 95.0, (1, 1, nlat, nlon)) * np.ones((1, nlev, 1, 1))
+    T64 = T.astype(np.float64, copy=False)
+    T0, Ti = 273.16, 250.16
+    alpha = np.where(T64 >= T0, 1.0, np.where(T64 <= Ti, 0.0, ((T64 - Ti) / (T0 - Ti)) ** 2))
+    es = (alpha * 611.21 * np.exp(17.502 * (T64 - T0) / (T64 - 32.19)) +
+          (1 - alpha) * 611.21 * np.exp(22.587 * (T64 - T0) / (T64 + 0.7)))
+    del alpha, T64
+    e = rh / 100.0 * es
+    del es
+    QV = (0.622 * e / (pa - 0.378 * e)).astype(dt, copy=False)
+    del e, pa
+    U = noise4(10.0, nlev) if noise else np.full((1, nlev, nlat, nlon), 5.0, dtype=dt)
+    V = noise4(10.0, nlev) if noise else np.full((1, nlev, nlat, nlon), -3.0, dtype=dt)
+
+    sic = np.clip(_smooth2d(rng, nlat, nlon) * 1.5 - 0.7, 0, 1)
+    sic = np.where(land > 0.5, np.nan, sic)
+    soil1 = np.array([0.035, 0.175, 0.64, 1.945])[:nsoil]
+    t_skin = 288.0 - 0.0065 * orog + rng.standard_normal((nlat, nlon))
+    era = dict(
+        ak=ak, bk=bk,
+        PS=ps[None].astype(dt), FIS=fis[None].astype(dt), T=T, QV=QV, U=U, V=V,
+        T_SKIN=t_skin[None].astype(dt),
+        T_SO=(t_skin[None, None] + np.zeros((1, nsoil, 1, 1))).astype(dt),
+        FR_LAND=land[None].astype(dt), FR_SEA_ICE=sic[None].astype(dt),
+        soil1=soil1, level=np.arange(1, nlev + 1), level1=np.arange(1, nlev + 2),
+    )
+
+    # ---- monthly deltas on the ERA5 grid ------------------------------------------------
+    months = np.arange(12)
+    season = np.cos(2 * np.pi * (months - 0.5) / 12.0)          # (12,)
+    pat = _smooth2d(rng, nlat, nlon)                            # (lat,lon) in [0,1]
+    prof = np.clip(1.0 + 4.0 * np.exp(-((np.log(plev) - np.log(30000.0)) / 1.2) ** 2), 1.0, 5.0)
+    prof = np.where(plev < 10000.0, 1.0 - 3.0 * (1 - plev / 10000.0), prof)   # stratospheric cooling
+    d_ta = (prof[None, :, None, None] * (0.8 + 0.2 * season[:, None, None, None]) *
+            (0.8 + 0.4 * pat[None, None]))
+    d_hur = 5.0 * (2 * _smooth2d(rng, nlat, nlon)[None, None] - 1) * \
+        np.cos(np.linspace(0, np.pi, S))[None, :, None, None] * (1 + 0.2 * season[:, None, None, None])
+    d_ua = 2.0 * (2 * _smooth2d(rng, nlat, nlon)[None, None] - 1) * np.ones((12, S, 1, 1))
+    d_va = 2.0 * (2 * _smooth2d(rng, nlat, nlon)[None, None] - 1) * np.ones((12, S, 1, 1))
+    # geopotential-height delta consistent with a warmer column: grows with height
+    h = np.clip(np.log(100000.0 / plev) / np.log(100000.0 / 100.0), 0, 1)
+    d_zg = (20.0 + 100.0 * h[None, :, None, None] ** 0.7) * (0.9 + 0.2 * pat[None, None]) * \
+        (1 + 0.1 * season[:, None, None, None])
+    d_tas = 2.0 * (0.8 + 0.2 * season[:, None, None]) * (0.8 + 0.4 * pat[None])
+    d_hurs = -2.0 * (2 * pat[None] - 1) * np.ones((12, 1, 1))
+    d_ts = d_tas * 1.05
+    d_tos = np.where(land[None] > 0.5, np.nan, 0.8 * d_tas)
+    d_sic = -20.0 * np.clip(_smooth2d(rng, nlat, nlon), 0, 1)[None] * np.ones((12, 1, 1))
+    ps_hist = ps[None] * (1 + 0.002 * (2 * _smooth2d(rng, nlat, nlon)[None] - 1)) * np.ones((12, 1, 1))
+    deltas = dict(ta=d_ta, hur=d_hur, ua=d_ua, va=d_va, zg=d_zg, tas=d_tas, hurs=d_hurs,
+                  ts=d_ts, tos=d_tos, siconc=d_sic, ps_hist=ps_hist)
+    deltas = {k: np.ascontiguousarray(v).astype(dt) for k, v in deltas.items()}
+    delta_times = np.array(['1995-%02d-15T12:00:00' % (m + 1) for m in months], dtype='datetime64[s]')
+    if target_dt is None:
+        target_dt = _dt.datetime(2006, 8, 2, 3)
+    lat = np.linspace(-90, 90, nlat) if nlat > 1 else np.array([0.0])
+    lon = np.arange(nlon) * (360.0 / nlon)
+    return dict(era=era, deltas=deltas, delta_times=delta_times, plev=plev,
+                target_dt=target_dt, lat=lat, lon=lon)
+
+
+def make_gcm_grid_case(nlat_src=48, nlon_src=96, nlat=37, nlon=72, nplev=5, ntime=3, seed=0,
+                       dtype=np.float64):
+    """step_02 regridding case: Gaussian-like source lats that do not reach the poles, periodic
+    source lons starting at 0; target regular grid including +-90 (cfg 4)."""
+    rng = np.random.default_rng(seed)
+    # Gaussian-like: ascending, nearly equally spaced, first/last row half a cell off the pole
+    x = (np.arange(nlat_src) + 0.5) / nlat_src
+    src_lat = (-90.0 + 180.0 * x)
+    src_lat = src_lat * (1 - 0.3 / nlat_src)
+    src_lon = np.arange(nlon_src) * (360.0 / nlon_src)
+    targ_lat = np.linspace(-90.0, 90.0, nlat)
+    targ_lon = np.arange(nlon) * (360.0 / nlon)
+    f = rng.standard_normal((ntime, nplev, nlat_src, nlon_src)).astype(dtype)
+    return dict(field=f, src_lat=src_lat, src_lon=src_lon, targ_lat=targ_lat, targ_lon=targ_lon)
