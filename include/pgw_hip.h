@@ -1,0 +1,250 @@
+/*
+ * pgw_hip.h  --  C-ABI of libpgw_hip.so: the MI355X (gfx950) compute path for the
+ * PGW4ERA5 step_03 / step_02 hot path.
+ *
+ * Every entry point replaces one piece of the reference's Python interface; the
+ * citation after each declaration is the reference file:line it stands in for
+ * (paths relative to the reference repository root).  The reference has no FFI of
+ * its own (it is pure Python); the binding a maintainer adds is the ctypes stub shown
+ * in INTEGRATION.md (pgw4era5_amd/_lib.py is that stub in full).
+ *
+ * Conventions
+ *  - plain C: opaque context, raw pointers, sizes; no C++/torch types.
+ *  - all `field` pointers are DEVICE pointers (from pgw_malloc or any hipMalloc'd
+ *    buffer, e.g. a torch tensor's data_ptr()); small coefficient vectors (ak, bk,
+ *    plev, coordinate tables) are HOST pointers, copied by the call.
+ *  - `dtype` is the STORAGE type of field arrays (PGW_F32 / PGW_F64); arithmetic is
+ *    always IEEE fp64, no fast-math.
+ *  - 4-D fields are C-order (time, level, lat, lon); `ncol` = nlat*nlon; pressure
+ *    ascends with the level index (functions.py:500-503 of the reference).
+ *  - calls on one context are stream-ordered on the context's HIP stream and are not
+ *    re-entrant; functions that report data errors synchronise before returning.
+ *  - return value: 0 = PGW_OK, otherwise a pgw_status code; pgw_last_error() gives
+ *    the text, pgw_error_column() the first offending column (or -1).
+ */
+#ifndef PGW_HIP_H
+#define PGW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgw_ctx pgw_ctx;
+
+enum pgw_status {
+    PGW_OK = 0,
+    PGW_ERR_HIP = 1,                 /* HIP runtime failure (text in pgw_last_error)            */
+    PGW_ERR_ARG = 2,                 /* bad argument / shape (functions.py:407-412,457-465)     */
+    PGW_ERR_SRC_NOT_ASCENDING = 10,  /* 'Source pressure values must be ascending!'  :500-501   */
+    PGW_ERR_TARG_NOT_ASCENDING = 11, /* 'Target pressure values must be ascending!'  :502-503   */
+    PGW_ERR_EXTRAP_OFF = 12,         /* 'Extrapolation deactivated but data out of bounds.' :564 */
+    PGW_ERR_PREF_BELOW_SURFACE = 13, /* 'p_ref locally lies below the surface...'    :162-165   */
+    PGW_ERR_PREF_AT_TOP = 14,        /* k* = 0: tav.sel(level=0) KeyError            :176       */
+    PGW_ERR_PS_HIST_ABOVE_TOP = 15,  /* replace_delta_sfc ValueError()               :360-363   */
+    PGW_ERR_TOP_PRESSURE = 16,       /* 'ERA5 top pressure is lower than ...'        :417-425   */
+    PGW_ERR_NOT_CONVERGED = 17,      /* 'Pressure adjustment did not converge' step_03:313-319  */
+    PGW_ERR_GRID_EXTENT = 18         /* regrid: target exceeds source    functions.py:845-888   */
+};
+
+enum pgw_dtype { PGW_F32 = 0, PGW_F64 = 1 };
+
+/* interp_logp_4d `extrapolate` argument (functions.py:434-446) */
+enum pgw_extrap { PGW_EXTRAP_OFF = 0, PGW_EXTRAP_LINEAR = 1, PGW_EXTRAP_CONSTANT = 2, PGW_EXTRAP_NAN = 3 };
+
+/* kernel ids for the per-context launch profiler (pgw_profile_*) */
+enum pgw_kernel_id {
+    PGW_K_PRESSURE = 0, PGW_K_Q_TO_RH = 1, PGW_K_RH_TO_Q = 2, PGW_K_INTEG_GEOPOT = 3,
+    PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
+    PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
+    PGW_K_COUNT = 11
+};
+
+/* ---------------------------------------------------------------- context ------------ */
+/* One context = one HIP device + one stream; replaces the implicit per-process state of a
+ * reference worker (parallel.py:18-32: one process per file, no shared state). */
+int pgw_device_count(int *n);
+int pgw_ctx_create(int device, pgw_ctx **out);
+int pgw_ctx_destroy(pgw_ctx *ctx);
+const char *pgw_last_error(pgw_ctx *ctx);
+long long pgw_error_column(pgw_ctx *ctx);
+const char *pgw_version(void);
+int pgw_device_name(pgw_ctx *ctx, char *buf, size_t len);
+
+/* ---------------------------------------------------------------- memory / stream ---- */
+int pgw_malloc(pgw_ctx *ctx, size_t bytes, void **dptr);
+int pgw_free(pgw_ctx *ctx, void *dptr);
+int pgw_host_alloc(pgw_ctx *ctx, size_t bytes, void **hptr);      /* pinned host memory */
+int pgw_host_free(pgw_ctx *ctx, void *hptr);
+int pgw_memcpy_h2d(pgw_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async */
+int pgw_memcpy_d2h(pgw_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async */
+int pgw_memcpy_d2d(pgw_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async */
+int pgw_memset(pgw_ctx *ctx, void *dst, int value, size_t bytes);             /* async */
+int pgw_sync(pgw_ctx *ctx);
+int pgw_mem_info(pgw_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+
+/* HIP-event launch profiler: when enabled every kernel launched by this library is
+ * bracketed by two events on the context stream; pgw_profile_get synchronises and returns
+ * launch count and summed device time of kernel `kid` since the last reset. */
+int pgw_profile_enable(pgw_ctx *ctx, int on);
+int pgw_profile_reset(pgw_ctx *ctx);
+int pgw_profile_get(pgw_ctx *ctx, int kid, long long *launches, double *total_ms);
+int pgw_timer_start(pgw_ctx *ctx);                 /* event on the context stream */
+int pgw_timer_stop(pgw_ctx *ctx, double *ms);      /* records, synchronises, returns elapsed */
+
+/* ---------------------------------------------------------------- vertical grid ------ */
+/* Hybrid coefficients of the ERA5 file: ak, bk on half levels (nlev+1 values), akm/bkm on
+ * full levels (nlev values) or NULL -> 0.5*diff + lower, as step_03_apply_to_era.py:68-85.
+ * Host pointers; kept in the context until the next call. */
+int pgw_set_levels(pgw_ctx *ctx, int nlev, const double *ak, const double *bk,
+                   const double *akm, const double *bkm);
+int pgw_get_full_level_coeffs(pgw_ctx *ctx, double *akm_out, double *bkm_out);
+
+/* a1 "integ_pressure": pa_hl = ak + ps*bk ; pa = akm + ps*bkm
+ * (step_03_apply_to_era.py:64-66, 87-88, 196-199).  Either output may be NULL.
+ * ps (ntime, ncol) ; pa_hl (ntime, nlev+1, ncol) ; pa (ntime, nlev, ncol). */
+int pgw_pressure_levels(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                        const void *ps, void *pa_hl, void *pa);
+
+/* ---------------------------------------------------------------- humidity ----------- */
+/* a2 specific_to_relative_humidity(hus, pa, ta)   functions.py:107-116 (with :58-64,:74-105)
+ * a3 relative_to_specific_humidity(hur, pa, ta)   functions.py:118-125 (with :66-72)
+ * flat elementwise over n elements. */
+int pgw_specific_to_relative_humidity(pgw_ctx *ctx, int dtype, long long n,
+                                      const void *hus, const void *pa, const void *ta, void *hur);
+int pgw_relative_to_specific_humidity(pgw_ctx *ctx, int dtype, long long n,
+                                      const void *hur, const void *pa, const void *ta, void *hus);
+/* same, with pa = akm + ps*bkm rebuilt in registers instead of read (saves the 4-D pa array
+ * step_03:87-94 / :196-197,262-266 materialise).  fields (ntime, nlev, ncol), ps (ntime, ncol) */
+int pgw_specific_to_relative_humidity_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                                             const void *hus, const void *ps, const void *ta, void *hur);
+int pgw_relative_to_specific_humidity_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                                             const void *hur, const void *ps, const void *ta, void *hus);
+
+/* ---------------------------------------------------------------- integ_geopot ------- */
+/* a4 integ_geopot(pa_hl, zgs, ta, hus, level1, p_ref)     functions.py:128-189
+ * pa_hl (ntime, nlev+1, ncol); zgs (ntime, ncol); ta, hus (ntime, nlev, ncol);
+ * p_ref: scalar `p_ref`, or per-column field `p_ref_field` (ntime, ncol) when non-NULL;
+ * phi_ref (ntime, ncol) out.  nlev = number of full levels (level1 labels are 1..nlev+1).
+ * full_column != 0 reads every level of every column (signature-faithful traffic,
+ * (3*nlev+3)*ncol elements, exact for any pressure ordering); 0 is the caller's assertion
+ * that pressure ascends strictly with the level index, and lets a wave stop once all of its
+ * columns have passed p_ref (identical results under that assertion). */
+int pgw_integ_geopot(pgw_ctx *ctx, int dtype, int ntime, int nlev, long long ncol,
+                     const void *pa_hl, const void *zgs, const void *ta, const void *hus,
+                     double p_ref, const void *p_ref_field, void *phi_ref, int full_column);
+
+/* ---------------------------------------------------------------- interp_logp_4d ----- */
+/* a6 interp_logp_4d(var, source_P, targ_P, extrapolate)   functions.py:434-477 and the
+ * column kernels :479-580.  var, source_P (ntime, nsrc, ncol); targ_P, out (ntime, ntarg, ncol).
+ * logp_in == 0: pressures in, logs taken inside (:470-471) = interp_logp_4d;
+ * logp_in != 0: the arrays already hold ln p = interp_1d_for_timelatlon (:479-508) and, with
+ * ntime = ncol = 1, interp_extrap_1d (:511-580). */
+int pgw_interp_logp_4d(pgw_ctx *ctx, int dtype, int ntime, int nsrc, int ntarg, long long ncol,
+                       const void *var, const void *source_P, const void *targ_P,
+                       int extrapolate, int logp_in, void *out);
+
+/* ---------------------------------------------------------------- deltas ------------- */
+/* a7 the arithmetic of load_delta's time interpolation (functions.py:288-292 -> scipy
+ * interp1d linear): out = (v_after - v_before)/x_hi * x_new + v_before, flat over n. */
+int pgw_time_lerp(pgw_ctx *ctx, int dtype, long long n, const void *v_before, const void *v_after,
+                  double x_hi, double x_new, void *out);
+
+/* a8 vert_interp_delta(delta, target_P, delta_sfc, ps_hist, ignore_top)  functions.py:369-431
+ * (+ replace_delta_sfc :343-366, + the time lerp of load_delta, + `era + delta` of
+ * step_03_apply_to_era.py:170-173) fused per column.
+ *  plev (nplev, host): the delta file's plev coordinate in FILE order; it is reversed like :383-384.
+ *  delta_b / delta_a (nplev, ncol) per time: the two bracketing records (delta_a NULL, or
+ *    x_hi == 0 -> delta_b is used as is, functions.py:282-283); same for the optional
+ *    surface pairs dsfc_*, pshist_* (ntime, ncol) (NULL -> no surface insertion).
+ *  target pressure: targ_P (ntime, nlev_t, ncol) if non-NULL, else akm + ps*bkm from
+ *    pgw_set_levels with ps (ntime, ncol).
+ *  add_to (ntime, nlev_t, ncol) or NULL: out = add_to + delta_interp.
+ *  ignore_top != 0 skips the model-top check (:417-425). */
+int pgw_vert_interp_delta(pgw_ctx *ctx, int dtype, int ntime, int nplev, int nlev_t, long long ncol,
+                          const double *plev,
+                          const void *delta_b, const void *delta_a, double x_hi, double x_new,
+                          const void *dsfc_b, const void *dsfc_a,
+                          const void *pshist_b, const void *pshist_a,
+                          const void *targ_P, const void *ps,
+                          int ignore_top, const void *add_to, void *out);
+
+/* replace_delta_sfc(source_P, ps_hist, delta, delta_sfc)  functions.py:343-366, on many columns:
+ * plev_asc (nplev, host, ascending); delta (ntime, nplev, ncol) in ascending order;
+ * delta_sfc, ps_hist (ntime, ncol); outputs out_P, out_delta (ntime, nplev, ncol). */
+int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol,
+                          const double *plev_asc, const void *delta, const void *delta_sfc,
+                          const void *ps_hist, void *out_P, void *out_delta);
+
+/* ---------------------------------------------------------------- ps fixed-point loop - */
+/* a5 one pass of the loop body step_03_apply_to_era.py:192-308 for fixed p_ref, fused:
+ * delta_ps += adj_ps ; ps = PS + delta_ps ; pa, pa_hl ; hus = rh_to_q(hur_pgw, pa, ta_pgw) ;
+ * phi_ref_pgw = integ_geopot(...) ; err = (phi_ref_pgw - phi_ref_era) - dphi_clim ;
+ * adj_ps = -adj_factor*ps/(Rd*ta_pgw[lowest])*err ; max|err| (NaN skipped).
+ *  ta_pgw, hur_pgw (ntime, nlev, ncol) storage dtype; PS, FIS (ntime, ncol) storage dtype;
+ *  phi_ref_era, dphi_clim, delta_ps, adj_ps (ntime, ncol) DOUBLE (loop state is fp64);
+ *  p_ref_field (double, (ntime,ncol)) or NULL -> scalar p_ref.
+ *  max_abs_err (host out). */
+int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                       const void *ta_pgw, const void *hur_pgw, const void *PS, const void *FIS,
+                       const double *phi_ref_era, const double *dphi_clim,
+                       double *delta_ps, double *adj_ps,
+                       double p_ref, const double *p_ref_field, double adj_factor,
+                       double *max_abs_err);
+
+/* a5 the whole loop step_03_apply_to_era.py:182-319 with its control flow: passes until
+ * max|err| <= thresh; error when the pass counter exceeds max_n_iter (so at most
+ * max_n_iter-1 passes succeed); the adj_ps of the last pass is NOT applied.
+ *  T, QV: the ERA fields for phi_ref_era (computed once; it is constant for fixed p_ref);
+ *  dzg_pref (ntime, ncol) storage dtype: zg delta [m] at plev == p_ref (multiplied by g here);
+ *  outputs: ps_pgw (ntime, ncol), hus_pgw (ntime, nlev, ncol) storage dtype (either may be NULL),
+ *  n_iter, max_err_hist[max_n_iter] (host, may be NULL). */
+int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                       const void *PS, const void *FIS, const void *T, const void *QV,
+                       const void *ta_pgw, const void *hur_pgw, const void *dzg_pref,
+                       double p_ref, double adj_factor, double thresh, int max_n_iter,
+                       void *ps_pgw, void *hus_pgw, int *n_iter, double *max_err_hist);
+
+/* sum over columns and passes of the full levels the last pgw_adjust_ps_loop actually read
+ * (the pass kernel stops a wave above p_ref); used for the bytes-moved accounting. */
+unsigned long long pgw_last_levels_touched(pgw_ctx *ctx);
+
+/* ---------------------------------------------------------------- step_02 regridding - */
+/* a10 regrid_lat_lon, xarray branch (functions.py:774-789, 817-893): separable linear
+ * interpolation, latitude first then longitude, on tables the host derives from the
+ * coordinates (pole rows = zonal mean, periodic +-360 copies, scipy interp1d index rule).
+ *  src (nfield, nlat_s, nlon_s); out (nfield, nlat_t, nlon_t);
+ *  lat_lo/lat_hi (nlat_t): source row of the lower/upper neighbour in the EXTENDED ascending
+ *    latitude axis: -1 = south-pole row, nlat_s = north-pole row, else physical row index
+ *    (already un-flipped); lat_dx = x_new - x_lo, lat_Dx = x_hi - x_lo; lat_oob != 0 -> NaN.
+ *  lon_lo/lon_hi (nlon_t): physical source column (periodic copies folded); lon_dx, lon_Dx, lon_oob.
+ *  pole rows use the NaN-skipping zonal mean of physical row `south_row` / `north_row`. */
+int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, int nlat_s, int nlon_s,
+                        int nlat_t, int nlon_t, const void *src,
+                        const int *lat_lo, const int *lat_hi, const double *lat_dx, const double *lat_Dx,
+                        const int *lat_oob,
+                        const int *lon_lo, const int *lon_hi, const double *lon_dx, const double *lon_Dx,
+                        const int *lon_oob,
+                        int south_row, int north_row, void *out);
+
+/* ---------------------------------------------------------------- surface riders ----- */
+/* a9 step_03_apply_to_era.py:103-146 + integrate_tos functions.py:1145-1186, 2-D fields (n = ntime*ncol)
+ *  sic_out = clip(sic + dsic/100, 0, 1)
+ *  dts_comb = integrate_tos(dtos, dts, land, sic_out) ; tskin_out = tskin + dts_comb
+ *  tso_out[s] = tso[s] + clim + exp(-soil_depth[s]/2.8)*(dts_comb - clim)   (nsoil levels) */
+int pgw_surface_update(pgw_ctx *ctx, int dtype, int ntime, long long ncol, int nsoil,
+                       const double *soil_depth,
+                       const void *sic, const void *dsic, const void *dtos, const void *dts,
+                       const void *land, const void *ts_clim, const void *tskin, const void *tso,
+                       void *sic_out, void *dts_comb_out, void *tskin_out, void *tso_out);
+
+/* integrate_tos(tos_field, ts_field, land_frac, ice_frac)  functions.py:1145-1186, flat over n */
+int pgw_integrate_tos(pgw_ctx *ctx, int dtype, long long n, const void *tos, const void *ts,
+                      const void *land, const void *ice, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGW_HIP_H */

@@ -1,0 +1,138 @@
+"""
+ctypes binding of libpgw_hip.so (C-ABI: include/pgw_hip.h).
+
+This is the whole FFI layer: one `argtypes/restype` line per exported function, a loader
+that fails loudly, and the status-code -> exception mapping that reproduces the reference's
+error behaviour (ValueError with the reference's message).
+
+There is no CPU fallback.  If the library is missing or cannot be loaded, `load()` raises
+ImportError naming the build command; every compute entry point goes through `load()`.
+
+HIP-runtime note: when the process also uses torch (multi-GPU launcher: RCCL barrier),
+import torch BEFORE the first call here, so that libpgw_hip.so binds to the libamdhip64.so.7
+torch already loaded instead of a second copy from /opt/rocm.
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpgw_hip.so')
+
+PGW_F32, PGW_F64 = 0, 1
+EXTRAP = {'off': 0, 'linear': 1, 'constant': 2, 'nan': 3}
+KERNEL_IDS = dict(pressure=0, q_to_rh=1, rh_to_q=2, integ_geopot=3, interp_logp=4, time_lerp=5,
+                  vert_interp_delta=6, adjust_ps_step=7, regrid=8, surface=9, finalize=10)
+
+PGW_OK = 0
+PGW_ERR_HIP = 1
+PGW_ERR_ARG = 2
+PGW_ERR_PREF_AT_TOP = 14
+PGW_ERR_PS_HIST_ABOVE_TOP = 15
+
+_vp, _i, _ll, _d, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_double, C.c_size_t
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol declared in include/pgw_hip.h
+SIGNATURES = {
+    'pgw_device_count': (_i, [_ip]),
+    'pgw_ctx_create': (_i, [_i, C.POINTER(_vp)]),
+    'pgw_ctx_destroy': (_i, [_vp]),
+    'pgw_last_error': (C.c_char_p, [_vp]),
+    'pgw_error_column': (_ll, [_vp]),
+    'pgw_version': (C.c_char_p, []),
+    'pgw_device_name': (_i, [_vp, C.c_char_p, _sz]),
+    'pgw_malloc': (_i, [_vp, _sz, C.POINTER(_vp)]),
+    'pgw_free': (_i, [_vp, _vp]),
+    'pgw_host_alloc': (_i, [_vp, _sz, C.POINTER(_vp)]),
+    'pgw_host_free': (_i, [_vp, _vp]),
+    'pgw_memcpy_h2d': (_i, [_vp, _vp, _vp, _sz]),
+    'pgw_memcpy_d2h': (_i, [_vp, _vp, _vp, _sz]),
+    'pgw_memcpy_d2d': (_i, [_vp, _vp, _vp, _sz]),
+    'pgw_memset': (_i, [_vp, _vp, _i, _sz]),
+    'pgw_sync': (_i, [_vp]),
+    'pgw_mem_info': (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    'pgw_profile_enable': (_i, [_vp, _i]),
+    'pgw_profile_reset': (_i, [_vp]),
+    'pgw_profile_get': (_i, [_vp, _i, C.POINTER(_ll), _dp]),
+    'pgw_timer_start': (_i, [_vp]),
+    'pgw_timer_stop': (_i, [_vp, _dp]),
+    'pgw_set_levels': (_i, [_vp, _i, _dp, _dp, _dp, _dp]),
+    'pgw_get_full_level_coeffs': (_i, [_vp, _dp, _dp]),
+    'pgw_pressure_levels': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp]),
+    'pgw_specific_to_relative_humidity': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp]),
+    'pgw_relative_to_specific_humidity': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp]),
+    'pgw_specific_to_relative_humidity_hybrid': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp]),
+    'pgw_relative_to_specific_humidity_hybrid': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp]),
+    'pgw_integ_geopot': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _d, _vp, _vp, _i]),
+    'pgw_interp_logp_4d': (_i, [_vp, _i, _i, _i, _i, _ll, _vp, _vp, _vp, _i, _i, _vp]),
+    'pgw_time_lerp': (_i, [_vp, _i, _ll, _vp, _vp, _d, _d, _vp]),
+    'pgw_vert_interp_delta': (_i, [_vp, _i, _i, _i, _i, _ll, _dp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _i, _vp, _vp]),
+    'pgw_replace_delta_sfc': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _vp, _vp, _vp]),
+    'pgw_integrate_tos': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp]),
+    'pgw_adjust_ps_step': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _dp]),
+    'pgw_adjust_ps_loop': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i,
+                                _vp, _vp, _ip, _dp]),
+    'pgw_last_levels_touched': (C.c_ulonglong, [_vp]),
+    'pgw_regrid_bilinear': (_i, [_vp, _i, _ll, _i, _i, _i, _i, _vp, _ip, _ip, _dp, _dp, _ip,
+                                 _ip, _ip, _dp, _dp, _ip, _i, _i, _vp]),
+    'pgw_surface_update': (_i, [_vp, _i, _i, _ll, _i, _dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class PGWHipError(RuntimeError):
+    """HIP runtime failure or bad argument reported by libpgw_hip.so."""
+
+
+def load():
+    """Load libpgw_hip.so and bind every symbol.  Raises ImportError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libpgw_hip.so is not built (%s). Build it with '
+            '`make -C pgw4era5_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`. '
+            'pgw4era5_amd has no CPU fallback.' % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if 'torch' not in sys.modules else C.RTLD_LOCAL)
+    except OSError as e:
+        raise ImportError('cannot load %s: %s (is the ROCm runtime libamdhip64.so.7 on the '
+                          'library path?)' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            f = getattr(lib, name)
+        except AttributeError:
+            raise ImportError('libpgw_hip.so does not export %s - rebuild it' % name)
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc):
+    """Map a pgw_status to the exception the reference raises at that point."""
+    if rc == PGW_OK:
+        return
+    lib = load()
+    msg = lib.pgw_last_error(ctx_handle)
+    msg = msg.decode() if msg else 'error %d' % rc
+    col = lib.pgw_error_column(ctx_handle) if ctx_handle else -1
+    if rc == PGW_ERR_HIP:
+        raise PGWHipError(msg)
+    if rc == PGW_ERR_PREF_AT_TOP:
+        raise KeyError(0)                       # tav.sel(level=0), functions.py:176
+    if rc == PGW_ERR_PS_HIST_ABOVE_TOP:
+        e = ValueError()                        # bare ValueError(), functions.py:360-361
+        e.column = col
+        e.detail = msg
+        raise e
+    e = ValueError(msg)                         # all other data errors are ValueError
+    e.status = rc
+    e.column = col
+    raise e

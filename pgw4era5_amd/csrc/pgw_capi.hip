@@ -1,0 +1,870 @@
+// pgw_capi.hip -- C-ABI (include/pgw_hip.h) over the gfx950 kernels in pgw_kernels.h.
+// Built as libpgw_hip.so with hipcc --offload-arch=gfx950 (pgw4era5_amd/csrc/Makefile).
+#include "../../include/pgw_hip.h"
+#include "pgw_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace pgw;
+
+struct ProfRec { int kid; hipEvent_t e0, e1; };
+
+struct pgw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    long long err_col = -1;
+    DevStatus *d_status = nullptr;     // device
+    DevStatus *h_status = nullptr;     // pinned host mirror
+    // vertical grid
+    int nlev = 0;
+    double *d_levels = nullptr;        // ak | bk | akm | bkm
+    std::vector<double> h_akm, h_bkm;
+    double ps_mono_min = 0.0;
+    // plev table cache for vert_interp_delta
+    std::vector<double> plev_key;
+    PlevTable plev_tab;
+    double *d_small = nullptr;         // small scratch (tables), 64 KiB
+    // named workspaces grown on demand
+    void *ws[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t ws_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // profiler
+    bool prof_on = false;
+    std::vector<ProfRec> prof_pending;
+    long long prof_count[PGW_K_COUNT];
+    double prof_ms[PGW_K_COUNT];
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    unsigned long long last_levels_touched = 0;
+};
+
+static const size_t SMALL_BYTES = 64 * 1024;
+
+static int fail(pgw_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, PGW_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+#define NEED(ctx, cond, msg)                                                                       \
+    do {                                                                                           \
+        if (!(cond)) return fail(ctx, PGW_ERR_ARG, "%s: %s", __func__, msg);                       \
+    } while (0)
+
+static const char *status_text(int code) {
+    switch (code) {
+        case PGW_ERR_SRC_NOT_ASCENDING: return "Source pressure values must be ascending!";
+        case PGW_ERR_TARG_NOT_ASCENDING: return "Target pressure values must be ascending!";
+        case PGW_ERR_EXTRAP_OFF: return "Extrapolation deactivated but data out of bounds.";
+        case PGW_ERR_PREF_BELOW_SURFACE:
+            return "p_ref locally lies below the surface. Please set a lower reference pressue (p_ref_inp) in settings.py";
+        case PGW_ERR_PREF_AT_TOP: return "p_ref is matched by the top half level (level 0 does not exist)";
+        case PGW_ERR_PS_HIST_ABOVE_TOP: return "historical surface pressure is not below the top climate-delta pressure level";
+        case PGW_ERR_TOP_PRESSURE:
+            return "ERA5 top pressure is lower than climate delta top pressure. If you are certain that you do not need "
+                   "the data beyond to upper-most pressure level of the climate delta, you can set the flag "
+                   "--ignore_top_pressure_error and re-run the script.";
+        case PGW_ERR_NOT_CONVERGED: return "ERROR! Pressure adjustment did not converge";
+        case PGW_ERR_GRID_EXTENT: return "ERA5 dataset extends further than GCM dataset!";
+        default: return "error";
+    }
+}
+
+// ------------------------------------------------------------------ launch helpers
+struct Prof {
+    pgw_ctx *c; int kid; hipEvent_t e0 = nullptr, e1 = nullptr;
+    Prof(pgw_ctx *c_, int kid_) : c(c_), kid(kid_) {
+        if (c->prof_on) {
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, c->stream);
+        }
+    }
+    ~Prof() {
+        if (c->prof_on) {
+            hipEventRecord(e1, c->stream);
+            c->prof_pending.push_back({kid, e0, e1});
+        }
+    }
+};
+
+static int prof_resolve(pgw_ctx *ctx) {
+    if (ctx->prof_pending.empty()) return PGW_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &r : ctx->prof_pending) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        ctx->prof_count[r.kid] += 1;
+        ctx->prof_ms[r.kid] += ms;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    ctx->prof_pending.clear();
+    return PGW_OK;
+}
+
+static inline unsigned int nblocks(long long n, int per) { return (unsigned int)((n + per - 1) / per); }
+
+static inline bool aligned16(const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+
+// columns per thread: 16 B per lane when shape and alignment allow, else 1
+static int pick_vec(int dtype, long long ncol, std::initializer_list<const void *> ptrs) {
+    int v = (dtype == PGW_F64) ? 2 : 4;
+    if (ncol % v != 0) return 1;
+    for (const void *p : ptrs) if (!aligned16(p)) return 1;
+    return v;
+}
+
+static int status_reset(pgw_ctx *ctx) {
+    DevStatus z;
+    memset(&z, 0, sizeof(z));
+    z.col = ~0ull;
+    z.min_targ_bits = ~0ull;
+    z.min_src_bits = ~0ull;
+    *ctx->h_status = z;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_status, ctx->h_status, sizeof(DevStatus), hipMemcpyHostToDevice, ctx->stream));
+    return PGW_OK;
+}
+static int status_fetch(pgw_ctx *ctx) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGW_OK;
+}
+static int status_check(pgw_ctx *ctx) {
+    int rc = status_fetch(ctx);
+    if (rc) return rc;
+    if (ctx->h_status->code != 0) {
+        ctx->err_col = (long long)ctx->h_status->col;
+        ctx->err = status_text(ctx->h_status->code);
+        return ctx->h_status->code;
+    }
+    return PGW_OK;
+}
+
+static int ws_get(pgw_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->ws[slot])); }
+        ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->ws[slot], bytes));
+        ctx->ws_bytes[slot] = bytes;
+    }
+    *out = ctx->ws[slot];
+    return PGW_OK;
+}
+
+static Levels levels_of(pgw_ctx *ctx) {
+    Levels lv;
+    int n = ctx->nlev;
+    lv.ak = ctx->d_levels;
+    lv.bk = ctx->d_levels + (n + 1);
+    lv.akm = ctx->d_levels + 2 * (n + 1);
+    lv.bkm = ctx->d_levels + 2 * (n + 1) + n;
+    lv.nlev = n;
+    lv.ps_mono_min = ctx->ps_mono_min;
+    return lv;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" const char *pgw_version(void) { return "pgw_hip 0.1.0 (gfx950)"; }
+
+extern "C" int pgw_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return PGW_ERR_HIP; }
+    *n = c;
+    return PGW_OK;
+}
+
+extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
+    if (!out) return PGW_ERR_ARG;
+    *out = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return PGW_ERR_HIP;
+    if (device < 0 || device >= cnt) return PGW_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return PGW_ERR_HIP;
+    pgw_ctx *c = new pgw_ctx();
+    c->device = device;
+    memset(c->prof_count, 0, sizeof(c->prof_count));
+    memset(c->prof_ms, 0, sizeof(c->prof_ms));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&c->d_status, sizeof(DevStatus)) != hipSuccess ||
+        hipHostMalloc(&c->h_status, sizeof(DevStatus)) != hipSuccess ||
+        hipMalloc(&c->d_small, SMALL_BYTES) != hipSuccess ||
+        hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
+        delete c;
+        return PGW_ERR_HIP;
+    }
+    *out = c;
+    return PGW_OK;
+}
+
+extern "C" int pgw_ctx_destroy(pgw_ctx *ctx) {
+    if (!ctx) return PGW_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (int i = 0; i < 8; ++i) if (ctx->ws[i]) hipFree(ctx->ws[i]);
+    if (ctx->d_levels) hipFree(ctx->d_levels);
+    if (ctx->d_small) hipFree(ctx->d_small);
+    if (ctx->d_status) hipFree(ctx->d_status);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->t0) hipEventDestroy(ctx->t0);
+    if (ctx->t1) hipEventDestroy(ctx->t1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PGW_OK;
+}
+
+extern "C" const char *pgw_last_error(pgw_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" long long pgw_error_column(pgw_ctx *ctx) { return ctx ? ctx->err_col : -1; }
+
+extern "C" int pgw_device_name(pgw_ctx *ctx, char *buf, size_t len) {
+    hipDeviceProp_t p;
+    HIPCHK(ctx, hipGetDeviceProperties(&p, ctx->device));
+    snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return PGW_OK;
+}
+
+// ------------------------------------------------------------------ memory
+extern "C" int pgw_malloc(pgw_ctx *ctx, size_t bytes, void **dptr) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return PGW_OK;
+}
+extern "C" int pgw_free(pgw_ctx *ctx, void *dptr) {
+    if (!dptr) return PGW_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(dptr));
+    return PGW_OK;
+}
+extern "C" int pgw_host_alloc(pgw_ctx *ctx, size_t bytes, void **hptr) {
+    HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16));
+    return PGW_OK;
+}
+extern "C" int pgw_host_free(pgw_ctx *ctx, void *hptr) {
+    if (hptr) HIPCHK(ctx, hipHostFree(hptr));
+    return PGW_OK;
+}
+extern "C" int pgw_memcpy_h2d(pgw_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return PGW_OK;
+}
+extern "C" int pgw_memcpy_d2h(pgw_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PGW_OK;
+}
+extern "C" int pgw_memcpy_d2d(pgw_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PGW_OK;
+}
+extern "C" int pgw_memset(pgw_ctx *ctx, void *dst, int value, size_t bytes) {
+    if (bytes) HIPCHK(ctx, hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return PGW_OK;
+}
+extern "C" int pgw_sync(pgw_ctx *ctx) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PGW_OK;
+}
+extern "C" int pgw_mem_info(pgw_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return PGW_OK;
+}
+
+// ------------------------------------------------------------------ profiler / timer
+extern "C" int pgw_profile_enable(pgw_ctx *ctx, int on) {
+    int rc = prof_resolve(ctx);
+    ctx->prof_on = on != 0;
+    return rc;
+}
+extern "C" int pgw_profile_reset(pgw_ctx *ctx) {
+    int rc = prof_resolve(ctx);
+    memset(ctx->prof_count, 0, sizeof(ctx->prof_count));
+    memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms));
+    return rc;
+}
+extern "C" int pgw_profile_get(pgw_ctx *ctx, int kid, long long *launches, double *total_ms) {
+    NEED(ctx, kid >= 0 && kid < PGW_K_COUNT, "bad kernel id");
+    int rc = prof_resolve(ctx);
+    if (launches) *launches = ctx->prof_count[kid];
+    if (total_ms) *total_ms = ctx->prof_ms[kid];
+    return rc;
+}
+extern "C" int pgw_timer_start(pgw_ctx *ctx) {
+    HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return PGW_OK;
+}
+extern "C" int pgw_timer_stop(pgw_ctx *ctx, double *ms) {
+    HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+    float f = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&f, ctx->t0, ctx->t1));
+    if (ms) *ms = f;
+    return PGW_OK;
+}
+
+// ------------------------------------------------------------------ vertical grid
+extern "C" int pgw_set_levels(pgw_ctx *ctx, int nlev, const double *ak, const double *bk,
+                              const double *akm, const double *bkm) {
+    NEED(ctx, nlev >= 1 && nlev <= 100000 && ak && bk, "bad level table");
+    NEED(ctx, (akm == nullptr) == (bkm == nullptr), "akm and bkm must both be given or both be NULL");
+    std::vector<double> h((size_t)4 * nlev + 2);
+    double *pak = h.data(), *pbk = pak + nlev + 1, *pakm = pbk + nlev + 1, *pbkm = pakm + nlev;
+    memcpy(pak, ak, sizeof(double) * (nlev + 1));
+    memcpy(pbk, bk, sizeof(double) * (nlev + 1));
+    for (int l = 0; l < nlev; ++l) {
+        if (akm) { pakm[l] = akm[l]; pbkm[l] = bkm[l]; }
+        else {   // step_03_apply_to_era.py:74-85: 0.5*diff(label='lower') + lower
+            pakm[l] = 0.5 * (ak[l + 1] - ak[l]) + ak[l];
+            pbkm[l] = 0.5 * (bk[l + 1] - bk[l]) + bk[l];
+        }
+    }
+    // smallest ps for which ak + ps*bk is strictly ascending over all layers:
+    // d(ak) + ps*d(bk) > 0.  Layers with d(bk) <= 0 need d(ak) + ps*d(bk) > 0 for all ps of
+    // interest; if d(bk) < 0 or (d(bk) == 0 and d(ak) <= 0) monotonicity is never assumed.
+    double pmin = 0.0;
+    for (int l = 0; l < nlev; ++l) {
+        double da = ak[l + 1] - ak[l], db = bk[l + 1] - bk[l];
+        if (db > 0) { double need = -da / db; if (need >= pmin) pmin = nextafter(need, INFINITY); }
+        else if (db == 0 && da > 0) { /* fine for every ps */ }
+        else { pmin = INFINITY; break; }
+    }
+    if (ctx->nlev != nlev || !ctx->d_levels) {
+        if (ctx->d_levels) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->d_levels)); ctx->d_levels = nullptr; }
+        HIPCHK(ctx, hipMalloc(&ctx->d_levels, sizeof(double) * h.size()));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_levels, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // h is a stack-lifetime buffer
+    ctx->nlev = nlev;
+    ctx->ps_mono_min = pmin;
+    ctx->h_akm.assign(pakm, pakm + nlev);
+    ctx->h_bkm.assign(pbkm, pbkm + nlev);
+    return PGW_OK;
+}
+
+extern "C" int pgw_get_full_level_coeffs(pgw_ctx *ctx, double *akm_out, double *bkm_out) {
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    memcpy(akm_out, ctx->h_akm.data(), sizeof(double) * ctx->nlev);
+    memcpy(bkm_out, ctx->h_bkm.data(), sizeof(double) * ctx->nlev);
+    return PGW_OK;
+}
+
+#define CHECK_COMMON(ctx, dtype, ntime, ncol)                                        \
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64"); \
+    NEED(ctx, ntime >= 1 && ncol >= 1, "ntime and ncol must be positive");
+
+// dispatch on storage dtype and vector width
+#define DISPATCH_TV(dtype, vec, ...)                                        \
+    do {                                                                    \
+        if (dtype == PGW_F64) {                                             \
+            typedef double T;                                               \
+            if (vec == 2) { constexpr int V = 2; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+        } else {                                                            \
+            typedef float T;                                                \
+            if (vec == 4) { constexpr int V = 4; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+        }                                                                   \
+    } while (0)
+
+#define DISPATCH_T(dtype, ...)                                   \
+    do {                                                         \
+        if (dtype == PGW_F64) { typedef double T; __VA_ARGS__; } \
+        else { typedef float T; __VA_ARGS__; }                   \
+    } while (0)
+
+extern "C" int pgw_pressure_levels(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                                   const void *ps, void *pa_hl, void *pa) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, ps && (pa_hl || pa), "null pointer");
+    int vec = pick_vec(dtype, ncol, {ps, pa_hl, pa});
+    Levels lv = levels_of(ctx);
+    {
+        Prof pr(ctx, PGW_K_PRESSURE);
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_pressure_levels<T, V>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                    dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ps, (T *)pa_hl, (T *)pa));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+// ------------------------------------------------------------------ humidity
+template <int MODE>
+static int humidity_flat(pgw_ctx *ctx, int kid, int dtype, long long n, const void *x, const void *pa,
+                         const void *ta, void *out) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, n >= 1 && x && pa && ta && out, "bad argument");
+    int vec = pick_vec(dtype, n, {x, pa, ta, out});
+    long long groups = n / vec;
+    unsigned int nb = nblocks(groups, BLOCK);
+    if (nb > 256 * 16) nb = 256 * 16;
+    {
+        Prof pr(ctx, kid);
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_humidity_flat<T, V, MODE>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n,
+                                                    (const T *)x, (const T *)pa, (const T *)ta, (T *)out));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+extern "C" int pgw_specific_to_relative_humidity(pgw_ctx *ctx, int dtype, long long n, const void *hus,
+                                                 const void *pa, const void *ta, void *hur) {
+    return humidity_flat<0>(ctx, PGW_K_Q_TO_RH, dtype, n, hus, pa, ta, hur);
+}
+extern "C" int pgw_relative_to_specific_humidity(pgw_ctx *ctx, int dtype, long long n, const void *hur,
+                                                 const void *pa, const void *ta, void *hus) {
+    return humidity_flat<1>(ctx, PGW_K_RH_TO_Q, dtype, n, hur, pa, ta, hus);
+}
+
+template <int MODE>
+static int humidity_hybrid(pgw_ctx *ctx, int kid, int dtype, int ntime, long long ncol, const void *x,
+                           const void *ps, const void *ta, void *out) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, x && ps && ta && out, "null pointer");
+    int vec = pick_vec(dtype, ncol, {x, ps, ta, out});
+    Levels lv = levels_of(ctx);
+    {
+        Prof pr(ctx, kid);
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_humidity_hybrid<T, V, MODE>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                    dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)x, (const T *)ps,
+                                                    (const T *)ta, (T *)out));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+extern "C" int pgw_specific_to_relative_humidity_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                                                        const void *hus, const void *ps, const void *ta, void *hur) {
+    return humidity_hybrid<0>(ctx, PGW_K_Q_TO_RH, dtype, ntime, ncol, hus, ps, ta, hur);
+}
+extern "C" int pgw_relative_to_specific_humidity_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
+                                                        const void *hur, const void *ps, const void *ta, void *hus) {
+    return humidity_hybrid<1>(ctx, PGW_K_RH_TO_Q, dtype, ntime, ncol, hur, ps, ta, hus);
+}
+
+// ------------------------------------------------------------------ integ_geopot
+static int launch_integ_geopot(pgw_ctx *ctx, int dtype, int nlev, int ntime, long long ncol, const void *pa_hl,
+                               const void *zgs, const void *ta, const void *hus, double p_ref,
+                               const void *p_ref_field, void *phi_ref, int full_column) {
+    int vec = pick_vec(dtype, ncol, {pa_hl, zgs, ta, hus, p_ref_field, phi_ref});
+    Prof pr(ctx, PGW_K_INTEG_GEOPOT);
+    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, 4>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,
+                                                (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,
+                                                (const T *)p_ref_field, (T *)phi_ref, full_column, ctx->d_status));
+    return PGW_OK;
+}
+
+extern "C" int pgw_integ_geopot(pgw_ctx *ctx, int dtype, int ntime, int nlev, long long ncol, const void *pa_hl,
+                                const void *zgs, const void *ta, const void *hus, double p_ref,
+                                const void *p_ref_field, void *phi_ref, int full_column) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nlev >= 1, "nlev must be positive");
+    NEED(ctx, pa_hl && zgs && ta && hus && phi_ref, "null pointer");
+    int rc = status_reset(ctx);
+    if (rc) return rc;
+    launch_integ_geopot(ctx, dtype, nlev, ntime, ncol, pa_hl, zgs, ta, hus, p_ref, p_ref_field, phi_ref, full_column);
+    HIPCHK(ctx, hipGetLastError());
+    return status_check(ctx);
+}
+
+// ------------------------------------------------------------------ interp_logp_4d
+template <typename T, int MODE>
+static int launch_interp_mode(pgw_ctx *ctx, int ntime, int S, int N, long long ncol, const T *var, const T *sp,
+                              const T *tp, T *out, int logp_in) {
+    long long total = (long long)ntime * ncol;
+    size_t per_thread = (size_t)2 * S * sizeof(double);
+    int tpb = (per_thread * 256 <= 64 * 1024) ? 256 : (per_thread * 128 <= 64 * 1024) ? 128 : 64;
+    size_t lds = per_thread * tpb;
+    if (lds > 160 * 1024) return fail(ctx, PGW_ERR_ARG, "interp_logp_4d: too many source levels (%d)", S);
+    Prof pr(ctx, PGW_K_INTERP_LOGP);
+#define LAUNCH_TPB(TPB)                                                                                            \
+    do {                                                                                                           \
+        if (lds > 64 * 1024)                                                                                       \
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_interp_logp<T, MODE, TPB>,                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL((k_interp_logp<T, MODE, TPB>), dim3(nblocks(total, TPB)), dim3(TPB), lds, ctx->stream,  \
+                           ntime, S, N, ncol, var, sp, tp, out, logp_in, ctx->d_status);                                    \
+    } while (0)
+    if (tpb == 256) LAUNCH_TPB(256); else if (tpb == 128) LAUNCH_TPB(128); else LAUNCH_TPB(64);
+#undef LAUNCH_TPB
+    return PGW_OK;
+}
+
+extern "C" int pgw_interp_logp_4d(pgw_ctx *ctx, int dtype, int ntime, int nsrc, int ntarg, long long ncol,
+                                  const void *var, const void *source_P, const void *targ_P, int extrapolate,
+                                  int logp_in, void *out) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nsrc >= 2 && ntarg >= 1, "need at least 2 source levels and 1 target level");
+    NEED(ctx, var && source_P && targ_P && out, "null pointer");
+    if (extrapolate < 0 || extrapolate > 3) return fail(ctx, PGW_ERR_ARG, "Invalid input value for \"extrapolate\"");
+    int rc = status_reset(ctx);
+    if (rc) return rc;
+    DISPATCH_T(dtype, {
+        const T *v = (const T *)var; const T *sp = (const T *)source_P; const T *tp = (const T *)targ_P; T *o = (T *)out;
+        switch (extrapolate) {
+            case 0: rc = launch_interp_mode<T, 0>(ctx, ntime, nsrc, ntarg, ncol, v, sp, tp, o, logp_in); break;
+            case 1: rc = launch_interp_mode<T, 1>(ctx, ntime, nsrc, ntarg, ncol, v, sp, tp, o, logp_in); break;
+            case 2: rc = launch_interp_mode<T, 2>(ctx, ntime, nsrc, ntarg, ncol, v, sp, tp, o, logp_in); break;
+            default: rc = launch_interp_mode<T, 3>(ctx, ntime, nsrc, ntarg, ncol, v, sp, tp, o, logp_in); break;
+        }
+    });
+    if (rc) return rc;
+    HIPCHK(ctx, hipGetLastError());
+    return status_check(ctx);
+}
+
+// ------------------------------------------------------------------ time lerp
+extern "C" int pgw_time_lerp(pgw_ctx *ctx, int dtype, long long n, const void *v_before, const void *v_after,
+                             double x_hi, double x_new, void *out) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, n >= 1 && v_before && v_after && out, "bad argument");
+    int vec = pick_vec(dtype, n, {v_before, v_after, out});
+    unsigned int nb = nblocks(n / vec, BLOCK);
+    if (nb > 256 * 16) nb = 256 * 16;
+    {
+        Prof pr(ctx, PGW_K_TIME_LERP);
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_time_lerp<T, V>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n,
+                                                    (const T *)v_before, (const T *)v_after, x_hi, x_new, (T *)out));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+// ------------------------------------------------------------------ vert_interp_delta
+static int plev_table(pgw_ctx *ctx, int nplev, const double *plev) {
+    if ((int)ctx->plev_key.size() == nplev && memcmp(ctx->plev_key.data(), plev, sizeof(double) * nplev) == 0)
+        return PGW_OK;
+    PlevTable &t = ctx->plev_tab;
+    memset(&t, 0, sizeof(t));
+    t.n = nplev;
+    t.pmax = -INFINITY; t.pmin = INFINITY;
+    bool anynan = false;
+    for (int i = 0; i < nplev; ++i) {
+        t.p[i] = plev[nplev - 1 - i];                       // functions.py:383-384 reversal
+        if (t.p[i] != t.p[i]) anynan = true;
+        if (t.p[i] > t.pmax) t.pmax = t.p[i];
+        if (t.p[i] < t.pmin) t.pmin = t.p[i];
+    }
+    if (anynan) return fail(ctx, PGW_ERR_ARG, "vert_interp_delta: NaN in plev");
+    // ln(plev) with the device log so that table and per-column logs are from one implementation
+    double *d_in = ctx->d_small, *d_out = ctx->d_small + MAX_PLEV;
+    HIPCHK(ctx, hipMemcpyAsync(d_in, t.p, sizeof(double) * nplev, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_log_table, dim3(1), dim3(64), 0, ctx->stream, nplev, d_in, d_out);
+    HIPCHK(ctx, hipMemcpyAsync(t.lnp, d_out, sizeof(double) * nplev, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->plev_key.assign(plev, plev + nplev);
+    return PGW_OK;
+}
+
+extern "C" int pgw_vert_interp_delta(pgw_ctx *ctx, int dtype, int ntime, int nplev, int nlev_t, long long ncol,
+                                     const double *plev, const void *delta_b, const void *delta_a, double x_hi,
+                                     double x_new, const void *dsfc_b, const void *dsfc_a, const void *pshist_b,
+                                     const void *pshist_a, const void *targ_P, const void *ps, int ignore_top,
+                                     const void *add_to, void *out) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nplev >= 2 && nplev <= MAX_PLEV, "nplev must be in [2, 64]");
+    NEED(ctx, plev && delta_b && out, "null pointer");
+    NEED(ctx, targ_P || ps, "need targ_P or ps");
+    NEED(ctx, (dsfc_b == nullptr) == (pshist_b == nullptr), "delta_sfc and ps_hist must be given together");
+    if (!targ_P) {
+        NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+        NEED(ctx, nlev_t == ctx->nlev, "nlev_t must equal the context's nlev when targ_P is NULL");
+    }
+    NEED(ctx, nlev_t >= 1, "nlev_t must be positive");
+    if (x_hi == 0.0) { delta_a = nullptr; dsfc_a = nullptr; pshist_a = nullptr; }
+    int rc = plev_table(ctx, nplev, plev);
+    if (rc) return rc;
+    rc = status_reset(ctx);
+    if (rc) return rc;
+    Levels lv = levels_of(ctx);
+    if (targ_P) { lv.akm = lv.bkm = nullptr; }
+    long long total = (long long)ntime * ncol;
+    {
+        Prof pr(ctx, PGW_K_VERT_INTERP_DELTA);
+        DISPATCH_T(dtype, {
+            DeltaSrc<T> d{(const T *)delta_b, (const T *)delta_a, x_hi, x_new};
+            DeltaSrc<T> s{(const T *)dsfc_b, (const T *)dsfc_a, x_hi, x_new};
+            DeltaSrc<T> p{(const T *)pshist_b, (const T *)pshist_a, x_hi, x_new};
+            if (dsfc_b)
+                hipLaunchKernelGGL((k_vert_interp_delta<T, true>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                                   ctx->plev_tab, lv, ntime, nlev_t, ncol, d, s, p, (const T *)targ_P, (const T *)ps,
+                                   ignore_top ? 0 : 1, (const T *)add_to, (T *)out, ctx->d_status);
+            else
+                hipLaunchKernelGGL((k_vert_interp_delta<T, false>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                                   ctx->plev_tab, lv, ntime, nlev_t, ncol, d, s, p, (const T *)targ_P, (const T *)ps,
+                                   ignore_top ? 0 : 1, (const T *)add_to, (T *)out, ctx->d_status);
+        });
+    }
+    HIPCHK(ctx, hipGetLastError());
+    rc = status_check(ctx);
+    if (rc) return rc;
+    if (!ignore_top) {
+        // functions.py:417-425: np.min(target_P) < np.min(source_P); NaN in either -> comparison False
+        DevStatus *h = ctx->h_status;
+        if (!h->nan_seen && h->min_targ_bits != ~0ull && h->min_src_bits != ~0ull) {
+            double mt, ms;
+            memcpy(&mt, &h->min_targ_bits, 8);
+            memcpy(&ms, &h->min_src_bits, 8);
+            if (mt < ms) { ctx->err = status_text(PGW_ERR_TOP_PRESSURE); ctx->err_col = -1; return PGW_ERR_TOP_PRESSURE; }
+        }
+    }
+    return PGW_OK;
+}
+
+extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol,
+                                     const double *plev_asc, const void *delta, const void *delta_sfc,
+                                     const void *ps_hist, void *out_P, void *out_delta) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nplev >= 1 && nplev <= MAX_PLEV, "nplev must be in [1, 64]");
+    NEED(ctx, plev_asc && delta && delta_sfc && ps_hist && out_P && out_delta, "null pointer");
+    PlevTable t;
+    memset(&t, 0, sizeof(t));
+    t.n = nplev; t.pmax = -INFINITY; t.pmin = INFINITY;
+    for (int i = 0; i < nplev; ++i) {
+        t.p[i] = plev_asc[i];
+        if (t.p[i] > t.pmax) t.pmax = t.p[i];
+        if (t.p[i] < t.pmin) t.pmin = t.p[i];
+    }
+    int rc = status_reset(ctx);
+    if (rc) return rc;
+    long long total = (long long)ntime * ncol;
+    {
+        Prof pr(ctx, PGW_K_VERT_INTERP_DELTA);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_replace_delta_sfc<T>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, t,
+                                             ntime, ncol, (const T *)delta, (const T *)delta_sfc, (const T *)ps_hist,
+                                             (T *)out_P, (T *)out_delta, ctx->d_status));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return status_check(ctx);
+}
+
+// ------------------------------------------------------------------ ps fixed-point loop
+static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *evap,
+                       const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
+                       double *delta_ps, double *adj_ps, double p_ref, const double *p_ref_field,
+                       double adj_factor, int full_column) {
+    int vec = pick_vec(dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field});
+    // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
+    Levels lv = levels_of(ctx);
+    Prof pr(ctx, PGW_K_ADJUST_PS_STEP);
+    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
+                                                (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
+                                                p_ref, p_ref_field, adj_factor, full_column, ctx->d_status));
+    return PGW_OK;
+}
+
+static double max_err_of(pgw_ctx *ctx) {
+    DevStatus *h = ctx->h_status;
+    if (h->valid == 0) return NAN;              // xarray .max() of an all-NaN field
+    double m;
+    memcpy(&m, &h->max_bits, 8);
+    return m;
+}
+
+static int full_column_env() {
+    const char *e = getenv("PGW_FULL_COLUMN");
+    return (e && e[0] == '1') ? 1 : 0;
+}
+
+extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta_pgw,
+                                  const void *hur_pgw, const void *PS, const void *FIS, const double *phi_ref_era,
+                                  const double *dphi_clim, double *delta_ps, double *adj_ps, double p_ref,
+                                  const double *p_ref_field, double adj_factor, double *max_abs_err) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, ta_pgw && hur_pgw && PS && FIS && phi_ref_era && dphi_clim && delta_ps && adj_ps, "null pointer");
+    size_t es = dtype == PGW_F64 ? 8 : 4;
+    void *evap = nullptr;
+    int rc = ws_get(ctx, 0, (size_t)ntime * ctx->nlev * ncol * es, &evap);
+    if (rc) return rc;
+    rc = humidity_hybrid<2>(ctx, PGW_K_RH_TO_Q, dtype, ntime, ncol, hur_pgw, PS, ta_pgw, evap);
+    if (rc) return rc;
+    rc = status_reset(ctx);
+    if (rc) return rc;
+    launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref,
+                p_ref_field, adj_factor, full_column_env());
+    HIPCHK(ctx, hipGetLastError());
+    rc = status_check(ctx);
+    if (max_abs_err) *max_abs_err = max_err_of(ctx);
+    return rc;
+}
+
+extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *PS,
+                                  const void *FIS, const void *T, const void *QV, const void *ta_pgw,
+                                  const void *hur_pgw, const void *dzg_pref, double p_ref, double adj_factor,
+                                  double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
+                                  double *max_err_hist) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, PS && FIS && T && QV && ta_pgw && hur_pgw && dzg_pref, "null pointer");
+    const int N = ctx->nlev;
+    const long long n2 = (long long)ntime * ncol;
+    const size_t es = dtype == PGW_F64 ? 8 : 4;
+    void *evap = nullptr, *state = nullptr, *pahl = nullptr;
+    int rc;
+    if ((rc = ws_get(ctx, 0, (size_t)ntime * N * ncol * es, &evap))) return rc;
+    if ((rc = ws_get(ctx, 1, (size_t)n2 * 4 * sizeof(double) + (size_t)n2 * es, &state))) return rc;
+    if ((rc = ws_get(ctx, 2, (size_t)ntime * (N + 1) * ncol * es, &pahl))) return rc;
+    double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
+    void *phi_era_t = (void *)(adj_ps + n2);
+    const int full_column = full_column_env();
+
+    // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it)
+    if ((rc = pgw_pressure_levels(ctx, dtype, ntime, ncol, PS, pahl, nullptr))) return rc;
+    if ((rc = status_reset(ctx))) return rc;
+    launch_integ_geopot(ctx, dtype, N, ntime, ncol, pahl, FIS, T, QV, p_ref, nullptr, phi_era_t, 1);
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = status_check(ctx))) return rc;
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((k_to_f64<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, (const T *)phi_era_t, phi_era);
+        hipLaunchKernelGGL((k_scale_to_f64<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, (const T *)dzg_pref,
+                           CON_G, dphi);                                   // step_03:292-293
+    });
+    HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
+    // e = hur_pgw/100 * e_sat(ta_pgw): iterate-independent part of :262-266
+    if ((rc = humidity_hybrid<2>(ctx, PGW_K_RH_TO_Q, dtype, ntime, ncol, hur_pgw, PS, ta_pgw, evap))) return rc;
+
+    double phi_ref_max_error = INFINITY;                                   // :186
+    int it = 1;                                                            // :188
+    unsigned long long touched = 0;
+    while (phi_ref_max_error > thresh) {                                   // :189
+        if ((rc = status_reset(ctx))) return rc;
+        launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
+                    adj_factor, full_column);
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = status_check(ctx))) return rc;
+        phi_ref_max_error = max_err_of(ctx);                               // :308
+        touched += ctx->h_status->levels_touched;
+        if (max_err_hist && it - 1 < max_n_iter) max_err_hist[it - 1] = phi_ref_max_error;
+        it += 1;                                                           // :313
+        if (it > max_n_iter) {                                             // :315-319
+            if (n_iter) *n_iter = it - 1;
+            ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
+            ctx->err_col = -1;
+            return PGW_ERR_NOT_CONVERGED;
+        }
+    }
+    ctx->last_levels_touched = touched;
+    if (n_iter) *n_iter = it - 1;
+    if (ps_pgw || hus_pgw) {
+        int vec = pick_vec(dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
+        Levels lv = levels_of(ctx);
+        Prof pr(ctx, PGW_K_FINALIZE);
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                                    ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
+                                                    (T *)ps_pgw, (T *)hus_pgw));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx->last_levels_touched; }
+
+// ------------------------------------------------------------------ regridding
+extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, int nlat_s, int nlon_s, int nlat_t,
+                                   int nlon_t, const void *src, const int *lat_lo, const int *lat_hi,
+                                   const double *lat_dx, const double *lat_Dx, const int *lat_oob, const int *lon_lo,
+                                   const int *lon_hi, const double *lon_dx, const double *lon_Dx, const int *lon_oob,
+                                   int south_row, int north_row, void *out) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, nfield >= 1 && nlat_s >= 2 && nlon_s >= 2 && nlat_t >= 1 && nlon_t >= 1, "bad shape");
+    NEED(ctx, src && out && lat_lo && lat_hi && lat_dx && lat_Dx && lat_oob && lon_lo && lon_hi && lon_dx && lon_Dx && lon_oob,
+         "null pointer");
+    NEED(ctx, south_row < nlat_s && north_row < nlat_s, "bad pole row");
+    for (int j = 0; j < nlat_t; ++j)
+        NEED(ctx, lat_oob[j] || (lat_lo[j] >= -1 && lat_lo[j] <= nlat_s && lat_hi[j] >= -1 && lat_hi[j] <= nlat_s), "lat index out of range");
+    for (int i = 0; i < nlon_t; ++i)
+        NEED(ctx, lon_oob[i] || (lon_lo[i] >= 0 && lon_lo[i] < nlon_s && lon_hi[i] >= 0 && lon_hi[i] < nlon_s), "lon index out of range");
+    // tables -> device workspace slot 3
+    size_t ti = sizeof(int) * (3 * (size_t)nlat_t + 3 * (size_t)nlon_t);
+    size_t td = sizeof(double) * (2 * (size_t)nlat_t + 2 * (size_t)nlon_t);
+    size_t tp = sizeof(double) * 2 * (size_t)nfield;
+    void *tab = nullptr;
+    int rc = ws_get(ctx, 3, td + tp + ti + 64, &tab);
+    if (rc) return rc;
+    std::vector<char> h(td + ti);
+    double *hd = (double *)h.data();
+    memcpy(hd, lat_dx, 8 * nlat_t); memcpy(hd + nlat_t, lat_Dx, 8 * nlat_t);
+    memcpy(hd + 2 * nlat_t, lon_dx, 8 * nlon_t); memcpy(hd + 2 * nlat_t + nlon_t, lon_Dx, 8 * nlon_t);
+    int *hi = (int *)(h.data() + td);
+    memcpy(hi, lat_lo, 4 * nlat_t); memcpy(hi + nlat_t, lat_hi, 4 * nlat_t); memcpy(hi + 2 * nlat_t, lat_oob, 4 * nlat_t);
+    int *hl = hi + 3 * nlat_t;
+    memcpy(hl, lon_lo, 4 * nlon_t); memcpy(hl + nlon_t, lon_hi, 4 * nlon_t); memcpy(hl + 2 * nlon_t, lon_oob, 4 * nlon_t);
+    double *dd = (double *)tab;
+    double *dpole = dd + 2 * nlat_t + 2 * nlon_t;
+    int *di = (int *)(dpole + 2 * nfield);
+    HIPCHK(ctx, hipMemcpyAsync(dd, hd, td, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(di, hi, ti, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    RegridTables tb;
+    tb.lat_dx = dd; tb.lat_Dx = dd + nlat_t; tb.lon_dx = dd + 2 * nlat_t; tb.lon_Dx = dd + 2 * nlat_t + nlon_t;
+    tb.lat_lo = di; tb.lat_hi = di + nlat_t; tb.lat_oob = di + 2 * nlat_t;
+    tb.lon_lo = di + 3 * nlat_t; tb.lon_hi = tb.lon_lo + nlon_t; tb.lon_oob = tb.lon_lo + 2 * nlon_t;
+    {
+        Prof pr(ctx, PGW_K_REGRID);
+        DISPATCH_T(dtype, {
+            if (south_row >= 0 || north_row >= 0)
+                hipLaunchKernelGGL((k_zonal_mean_rows<T>), dim3(nblocks(nfield * 2 * 64, BLOCK)), dim3(BLOCK), 0, ctx->stream, nfield,
+                                   nlat_s, nlon_s, (const T *)src, south_row, north_row, dpole);
+            unsigned int gz = (unsigned int)(nfield < 4096 ? nfield : 4096);
+            hipLaunchKernelGGL((k_regrid<T>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                               nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+        });
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+// ------------------------------------------------------------------ surface riders
+extern "C" int pgw_integrate_tos(pgw_ctx *ctx, int dtype, long long n, const void *tos, const void *ts,
+                                 const void *land, const void *ice, void *out) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, n >= 1 && tos && ts && land && ice && out, "bad argument");
+    {
+        Prof pr(ctx, PGW_K_SURFACE);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_integrate_tos<T>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, n,
+                                             (const T *)tos, (const T *)ts, (const T *)land, (const T *)ice, (T *)out));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+extern "C" int pgw_surface_update(pgw_ctx *ctx, int dtype, int ntime, long long ncol, int nsoil,
+                                  const double *soil_depth, const void *sic, const void *dsic, const void *dtos,
+                                  const void *dts, const void *land, const void *ts_clim, const void *tskin,
+                                  const void *tso, void *sic_out, void *dts_comb_out, void *tskin_out, void *tso_out) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nsoil >= 0 && nsoil <= MAX_SOIL, "nsoil must be in [0, 16]");
+    NEED(ctx, sic && dsic && dtos && dts && land, "null pointer");
+    NEED(ctx, !tskin_out || tskin, "tskin required for tskin_out");
+    NEED(ctx, !tso_out || (tso && ts_clim && soil_depth && nsoil > 0), "tso, ts_clim, soil_depth required for tso_out");
+    SoilTable st;
+    memset(&st, 0, sizeof(st));
+    st.n = nsoil;
+    for (int s = 0; s < nsoil; ++s) st.w[s] = exp(-soil_depth[s] / 2.8);      // step_03:140
+    long long n = (long long)ntime * ncol;
+    {
+        Prof pr(ctx, PGW_K_SURFACE);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_surface_update<T>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, ntime, ncol,
+                                              st, (const T *)sic, (const T *)dsic, (const T *)dtos, (const T *)dts, (const T *)land,
+                                              (const T *)ts_clim, (const T *)tskin, (const T *)tso, (T *)sic_out, (T *)dts_comb_out,
+                                              (T *)tskin_out, (T *)tso_out));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}

@@ -1,0 +1,111 @@
+// pgw_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Column kernels: one thread owns V adjacent (lat,lon) columns (V*sizeof(T) = 16 B where the
+// grid allows it), consecutive lanes own consecutive groups, so every level access of a wave is
+// one fully coalesced 1 KiB row segment of the (time, lev, lat, lon) C-order array.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgw {
+
+constexpr double CON_RD = 287.05;      // constants.py:3-7 of the reference
+constexpr double CON_G = 9.80665;
+constexpr double CON_MW_MD = 0.622;
+
+constexpr int BLOCK = 256;             // 4 waves of 64
+
+// device-resident status block of a context (zeroed before a launch that can report)
+struct DevStatus {
+    int code;                          // first pgw_status reported by a kernel
+    int nan_seen;                      // bit 0: NaN in target min, bit 1: NaN in source min
+    unsigned long long col;            // min offending column (init ~0ull)
+    unsigned long long max_bits;       // max |err| as ordered bits of a non-negative double
+    unsigned long long valid;          // number of non-NaN |err| contributions (>0 flag)
+    unsigned long long min_targ_bits;  // min target pressure (bits of positive double)
+    unsigned long long min_src_bits;   // min source pressure
+    unsigned long long levels_touched; // sum over columns of levels read (early-exit kernels)
+};
+
+template <typename T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
+
+template <typename T, int V>
+__device__ __forceinline__ void loadv(const T *__restrict__ p, double (&out)[V]) {
+    Pack<T, V> t = *reinterpret_cast<const Pack<T, V> *>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = (double)t.v[i];
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void storev(T *__restrict__ p, const double (&in)[V]) {
+    Pack<T, V> t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) t.v[i] = (T)in[i];
+    *reinterpret_cast<Pack<T, V> *>(p) = t;
+}
+
+__device__ __forceinline__ void report(DevStatus *st, int code, long long col) {
+    atomicMin(&st->col, (unsigned long long)col);
+    atomicCAS(&st->code, 0, code);
+}
+
+// ---- humidity thermodynamics (functions.py:58-125), operation order as written there ----
+__device__ __forceinline__ double esat_water(double ta) {   // :74-89 water
+    return 611.21 * exp(17.502 * (ta - 273.16) / (ta - 32.19));
+}
+__device__ __forceinline__ double esat_ice(double ta) {     // :74-89 ice (a4 = -0.7)
+    return 611.21 * exp(22.587 * (ta - 273.16) / (ta - (-0.7)));
+}
+// :91-105.  alpha = 1 (T>=T0), 0 (T<=Ti), ((T-Ti)/(T0-Ti))^2 in between, NaN for NaN T.
+// alpha*e_w + (1-alpha)*e_i is evaluated in full only in the mixed range; for alpha in {0,1}
+// the dropped term is exactly 0*finite = 0 for every finite T (e_w, e_i are finite for all
+// T > 32.19 K), so the value is unchanged.
+__device__ __forceinline__ double esat_mixed(double ta) {
+    const double T0 = 273.16, Ti = 250.16;
+    if (ta >= T0) return esat_water(ta);
+    if (ta <= Ti) {
+        if (ta > 40.0) return esat_ice(ta);
+        // unphysical cold: keep the literal expression (0*e_w may be NaN/inf there)
+        return 0.0 * esat_water(ta) + 1.0 * esat_ice(ta);
+    }
+    if (ta < T0 && ta > Ti) {
+        double r = (ta - Ti) / (T0 - Ti);
+        double alpha = r * r;                                   // np.power(x, 2.) == x*x
+        return alpha * esat_water(ta) + (1 - alpha) * esat_ice(ta);
+    }
+    return __builtin_nan("");                                   // NaN temperature
+}
+__device__ __forceinline__ double q_to_e(double hus, double pa) {          // :58-64
+    return hus * pa / (CON_MW_MD + 0.378 * hus);
+}
+__device__ __forceinline__ double e_to_q(double vapp, double pa) {         // :66-72
+    return CON_MW_MD * vapp / (pa - (1 - CON_MW_MD) * vapp);
+}
+__device__ __forceinline__ double q_to_rh(double hus, double pa, double ta) {   // :107-116
+    return (q_to_e(hus, pa) / esat_mixed(ta)) * 100;
+}
+__device__ __forceinline__ double rh_to_e(double hur, double ta) {         // :123
+    return hur / 100 * esat_mixed(ta);
+}
+__device__ __forceinline__ double rh_to_q(double hur, double pa, double ta) {   // :118-125
+    return e_to_q(rh_to_e(hur, ta), pa);
+}
+
+// functions.py:135  pa_hl.where(pa_hl > 0, 0.0001): NaN > 0 is False -> 1e-4
+__device__ __forceinline__ double fix_p(double p) { return (p > 0) ? p : 0.0001; }
+
+// ordered-bits view of a non-negative (or any positive) double for atomicMax/atomicMin
+__device__ __forceinline__ unsigned long long dbits(double x) { return (unsigned long long)__double_as_longlong(x); }
+
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off, 64));
+    return x;
+}
+__device__ __forceinline__ double wave_min(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmin(x, __shfl_xor(x, off, 64));
+    return x;
+}
+
+}  // namespace pgw

@@ -1,0 +1,795 @@
+// pgw_kernels.h -- hand-written gfx950 kernels for the PGW4ERA5 step_03 / step_02 hot path.
+// All arithmetic is IEEE fp64 (no fast-math); T is the storage type of field arrays.
+// Citations are reference file:line (functions.py unless prefixed).
+#pragma once
+#include "pgw_device.h"
+
+namespace pgw {
+
+// Vertical-grid tables of a context, in device memory; every access is wave-uniform
+// (index = level loop counter) so the compiler emits scalar (s_load) reads.
+struct Levels {
+    const double *ak;    // nlev+1
+    const double *bk;    // nlev+1
+    const double *akm;   // nlev
+    const double *bkm;   // nlev
+    int nlev;
+    double ps_mono_min;  // columns with ps >= this have strictly ascending half-level pressure
+};
+
+// flat column group -> (time, column) and base offsets
+struct ColIdx {
+    long long t, c;
+};
+__device__ __forceinline__ ColIdx col_index(long long g, int V, long long ncol) {
+    long long flat = g * V;
+    ColIdx r;
+    r.t = flat / ncol;
+    r.c = flat - r.t * ncol;
+    return r;
+}
+
+// =====================================================================================
+// a1  pressure on half / full levels          step_03_apply_to_era.py:64-66,87-88,196-199
+// write-bound: (2N+1) rows out per column, 1 element in.
+// =====================================================================================
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_pressure_levels(Levels lv, int ntime, long long ncol,
+                                                           const T *__restrict__ ps,
+                                                           T *__restrict__ pa_hl, T *__restrict__ pa) {
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    if (g >= ngroups) return;
+    ColIdx ix = col_index(g, V, ncol);
+    double p[V];
+    loadv<T, V>(ps + ix.t * ncol + ix.c, p);
+    const int N = lv.nlev;
+    if (pa_hl) {
+        T *o = pa_hl + ix.t * (N + 1) * ncol + ix.c;
+#pragma unroll 4
+        for (int k = 0; k <= N; ++k) {
+            double a = lv.ak[k], b = lv.bk[k], r[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) r[v] = a + p[v] * b;
+            storev<T, V>(o + (long long)k * ncol, r);
+        }
+    }
+    if (pa) {
+        T *o = pa + ix.t * N * ncol + ix.c;
+#pragma unroll 4
+        for (int l = 0; l < N; ++l) {
+            double a = lv.akm[l], b = lv.bkm[l], r[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) r[v] = a + p[v] * b;
+            storev<T, V>(o + (long long)l * ncol, r);
+        }
+    }
+}
+
+// =====================================================================================
+// a2 / a3  humidity conversions, flat elementwise             functions.py:107-125
+// MODE 0: q -> RH ; MODE 1: RH -> q ; MODE 2: RH -> e (vapour pressure, :123)
+// =====================================================================================
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_humidity_flat(long long n, const T *__restrict__ x,
+                                                         const T *__restrict__ pa,
+                                                         const T *__restrict__ ta, T *__restrict__ out) {
+    long long stride = (long long)gridDim.x * BLOCK;
+    for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g * V < n; g += stride) {
+        double a[V], p[V], t[V], r[V];
+        loadv<T, V>(x + g * V, a);
+        loadv<T, V>(pa + g * V, p);
+        loadv<T, V>(ta + g * V, t);
+#pragma unroll
+        for (int v = 0; v < V; ++v) r[v] = (MODE == 0) ? q_to_rh(a[v], p[v], t[v]) : rh_to_q(a[v], p[v], t[v]);
+        storev<T, V>(out + g * V, r);
+    }
+}
+
+// same with pa = akm + ps*bkm rebuilt in registers (no 4-D pressure array)
+template <typename T, int V, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_humidity_hybrid(Levels lv, int ntime, long long ncol,
+                                                           const T *__restrict__ x, const T *__restrict__ ps,
+                                                           const T *__restrict__ ta, T *__restrict__ out) {
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    if (g >= ngroups) return;
+    ColIdx ix = col_index(g, V, ncol);
+    double p[V];
+    loadv<T, V>(ps + ix.t * ncol + ix.c, p);
+    const int N = lv.nlev;
+    long long base = ix.t * N * ncol + ix.c;
+#pragma unroll 2
+    for (int l = 0; l < N; ++l) {
+        double a[V], t[V], r[V];
+        loadv<T, V>(x + base + (long long)l * ncol, a);
+        loadv<T, V>(ta + base + (long long)l * ncol, t);
+        double am = lv.akm[l], bm = lv.bkm[l];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            double pa = am + p[v] * bm;
+            r[v] = (MODE == 0) ? q_to_rh(a[v], pa, t[v]) : (MODE == 1) ? rh_to_q(a[v], pa, t[v]) : rh_to_e(a[v], t[v]);
+        }
+        storev<T, V>(out + base + (long long)l * ncol, r);
+    }
+}
+
+// =====================================================================================
+// a4  integ_geopot                                             functions.py:128-189
+// One thread = V columns, bottom-up scan; the half level k* with the smallest non-negative
+// p_hl - p_ref (ties -> lowest k, like nanargmin) is tracked while scanning, so non-monotone
+// columns give the reference's answer too.
+// =====================================================================================
+struct GeoAcc {            // per-column running state of the upward scan
+    double phi;            // phi at the lower half level of the current layer
+    double p_lo, lnp_lo;   // pressure / ln p at that half level
+    double dmin;           // smallest non-negative p_hl - p_ref so far
+    double phi_s, tv_s, lnp_s;
+    int kstar;             // -1 = none yet
+};
+
+__device__ __forceinline__ void geo_init(GeoAcc &a, double zgs, double p_bottom) {
+    a.phi = zgs;
+    a.p_lo = fix_p(p_bottom);
+    a.lnp_lo = log(a.p_lo);
+    a.dmin = __builtin_inf();
+    a.kstar = -1;
+    a.phi_s = a.tv_s = a.lnp_s = 0.0;
+}
+// process layer l (between half levels l and l+1); p_top = pa_hl[l] raw
+__device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double tv, double p_top, double p_ref) {
+    double d = a.p_lo - p_ref;                        // candidate k = l+1         :160-161
+    if (d >= 0 && d <= a.dmin) {
+        a.dmin = d; a.kstar = l + 1; a.phi_s = a.phi; a.tv_s = tv; a.lnp_s = a.lnp_lo;
+    }
+    double p_hi = fix_p(p_top);                       // :135
+    double lnp_hi = log(p_hi);
+    a.phi = a.phi + (CON_RD * tv) * (a.lnp_lo - lnp_hi);   // :149-152, dlnpa :136-138
+    a.p_lo = p_hi; a.lnp_lo = lnp_hi;
+}
+// returns phi_ref; reports errors
+__device__ __forceinline__ double geo_finish(GeoAcc &a, double p_ref, DevStatus *st, long long col) {
+    double d = a.p_lo - p_ref;                        // candidate k = 0
+    if (d >= 0 && d <= a.dmin) a.kstar = 0;
+    if (a.kstar < 0) { report(st, 13 /*PGW_ERR_PREF_BELOW_SURFACE*/, col); return __builtin_nan(""); }
+    if (a.kstar == 0) { report(st, 14 /*PGW_ERR_PREF_AT_TOP*/, col); return __builtin_nan(""); }
+    return a.phi_s - (CON_RD * a.tv_s) * (log(p_ref) - a.lnp_s);    // :174-179
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(BLOCK) void k_integ_geopot(int nlev, int ntime, long long ncol,
+                                                        const T *__restrict__ pa_hl, const T *__restrict__ zgs,
+                                                        const T *__restrict__ ta, const T *__restrict__ hus,
+                                                        double p_ref_s, const T *__restrict__ p_ref_f,
+                                                        T *__restrict__ phi_ref, int full_column,
+                                                        DevStatus *st) {
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    if (g >= ngroups) return;
+    ColIdx ix = col_index(g, V, ncol);
+    const int N = nlev;
+    const T *ph = pa_hl + ix.t * (N + 1) * ncol + ix.c;
+    const T *pt = ta + ix.t * N * ncol + ix.c;
+    const T *pq = hus + ix.t * N * ncol + ix.c;
+    long long c2 = ix.t * ncol + ix.c;
+    double z[V], pb[V], pref[V];
+    loadv<T, V>(zgs + c2, z);
+    loadv<T, V>(ph + (long long)N * ncol, pb);
+    if (p_ref_f) loadv<T, V>(p_ref_f + c2, pref);
+    else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
+    }
+    GeoAcc acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) geo_init(acc[v], z[v], pb[v]);
+    int l = N - 1;
+    // chunks of U levels: issue all 3*U row loads, then the dependent scan
+    for (; l >= U - 1; l -= U) {
+        double p[U][V], t[U][V], q[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            loadv<T, V>(ph + (long long)(l - u) * ncol, p[u]);
+            loadv<T, V>(pt + (long long)(l - u) * ncol, t[u]);
+            loadv<T, V>(pq + (long long)(l - u) * ncol, q[u]);
+        }
+        bool above = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                double tv = t[u][v] * (1 + 0.61 * q[u][v]);          // :144
+                geo_layer(acc[v], l - u, tv, p[u][v], pref[v]);
+            }
+        }
+        if (!full_column) {
+            // a column is finished once its pressure has dropped below p_ref and it has been
+            // strictly ascending so far (then no higher half level can satisfy p >= p_ref)
+#pragma unroll
+            for (int v = 0; v < V; ++v) above = above && (acc[v].p_lo < pref[v]) && (acc[v].kstar >= 0);
+            if (__all(above)) { l -= U; goto done; }
+        }
+    }
+    for (; l >= 0; --l) {
+        double p[V], t[V], q[V];
+        loadv<T, V>(ph + (long long)l * ncol, p);
+        loadv<T, V>(pt + (long long)l * ncol, t);
+        loadv<T, V>(pq + (long long)l * ncol, q);
+#pragma unroll
+        for (int v = 0; v < V; ++v) geo_layer(acc[v], l, t[v] * (1 + 0.61 * q[v]), p[v], pref[v]);
+    }
+done:
+    double r[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) r[v] = geo_finish(acc[v], pref[v], st, c2 + v);
+    storev<T, V>(phi_ref + c2, r);
+}
+
+// =====================================================================================
+// a5  fused pass of the surface-pressure loop         step_03_apply_to_era.py:192-308
+// The vapour pressure e = hur_pgw/100 * e_sat(ta_pgw) (functions.py:123) does not depend on
+// the iterate, so it is precomputed once per file (k_humidity_hybrid MODE 2) and each pass
+// does q = 0.622 e / (pa - 0.378 e) (:66-72) - the same values the reference recomputes.
+// State (delta_ps, adj_ps) and the constant phi_ref_era / dphi_clim are fp64.
+// =====================================================================================
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, long long ncol,
+                                                          const T *__restrict__ ta, const T *__restrict__ evap,
+                                                          const T *__restrict__ PS, const T *__restrict__ FIS,
+                                                          const double *__restrict__ phi_ref_era,
+                                                          const double *__restrict__ dphi_clim,
+                                                          double *__restrict__ delta_ps, double *__restrict__ adj_ps,
+                                                          double p_ref_s, const double *__restrict__ p_ref_f,
+                                                          double adj_factor, int full_column, DevStatus *st) {
+    __shared__ double s_max[BLOCK / 64];
+    __shared__ unsigned int s_valid[BLOCK / 64];
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    double amax = -1.0;       // max |err| of this thread's valid columns (-1 = none)
+    int touched = 0;          // full levels read by this thread (x V columns)
+    if (g < ngroups) {
+        ColIdx ix = col_index(g, V, ncol);
+        const int N = lv.nlev;
+        long long c2 = ix.t * ncol + ix.c;
+        const T *pt = ta + ix.t * N * ncol + ix.c;
+        const T *pe = evap + ix.t * N * ncol + ix.c;
+        double ps0[V], z[V], dps[V], adj[V], ps[V], pref[V], tlow[V];
+        loadv<T, V>(PS + c2, ps0);
+        loadv<T, V>(FIS + c2, z);
+        loadv<double, V>(delta_ps + c2, dps);
+        loadv<double, V>(adj_ps + c2, adj);
+        if (p_ref_f) loadv<double, V>(p_ref_f + c2, pref);
+        else {
+#pragma unroll
+            for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
+        }
+        GeoAcc acc[V];
+        bool mono[V];
+        {
+            double akN = lv.ak[N], bkN = lv.bk[N];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                dps[v] = dps[v] + adj[v];                       // step_03:192
+                ps[v] = ps0[v] + dps[v];                        // :193
+                geo_init(acc[v], z[v], akN + ps[v] * bkN);      // :198
+                mono[v] = ps[v] >= lv.ps_mono_min;              // false for NaN
+            }
+        }
+        storev<double, V>(delta_ps + c2, dps);
+        double tn[V], en[V];                                    // prefetched next level
+        loadv<T, V>(pt + (long long)(N - 1) * ncol, tn);
+        loadv<T, V>(pe + (long long)(N - 1) * ncol, en);
+#pragma unroll
+        for (int v = 0; v < V; ++v) tlow[v] = tn[v];            // ta_pgw at the lowest full level, :303
+        for (int l = N - 1; l >= 0; --l) {
+            double t[V], e[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { t[v] = tn[v]; e[v] = en[v]; }
+            if (l > 0) {
+                loadv<T, V>(pt + (long long)(l - 1) * ncol, tn);
+                loadv<T, V>(pe + (long long)(l - 1) * ncol, en);
+            }
+            double am = lv.akm[l], bm = lv.bkm[l], a = lv.ak[l], b = lv.bk[l];
+            bool above = true;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                double pa = am + ps[v] * bm;                    // :196
+                double q = e_to_q(e[v], pa);                    // :262-266
+                double tv = t[v] * (1 + 0.61 * q);              // functions.py:144
+                geo_layer(acc[v], l, tv, a + ps[v] * b, pref[v]);
+                above = above && mono[v] && (acc[v].p_lo < pref[v]) && (acc[v].kstar >= 0);
+            }
+            touched += V;
+            if (!full_column && __all(above)) break;
+        }
+        double nadj[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            double phi_ref = geo_finish(acc[v], pref[v], st, c2 + v);
+            double err = (phi_ref - phi_ref_era[c2 + v]) - dphi_clim[c2 + v];        // :289,298
+            nadj[v] = -adj_factor * ps[v] / (CON_RD * tlow[v]) * err;                 // :301-304
+            double ae = fabs(err);
+            if (ae == ae) amax = fmax(amax, ae);                                      // :308 skipna
+        }
+        storev<double, V>(adj_ps + c2, nadj);
+    }
+    // block max (exact: max is order independent) -> one atomic per block
+    double wm = wave_max(amax);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) touched += __shfl_xor(touched, off, 64);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_max[w] = wm; s_valid[w] = (unsigned int)touched; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = s_max[0];
+        unsigned long long tch = s_valid[0];
+#pragma unroll
+        for (int i = 1; i < BLOCK / 64; ++i) { m = fmax(m, s_max[i]); tch += s_valid[i]; }
+        if (m >= 0.0) {
+            atomicMax(&st->max_bits, dbits(m));
+            atomicAdd(&st->valid, 1ull);
+        }
+        atomicAdd(&st->levels_touched, tch);
+    }
+}
+
+// final outputs of the loop: ps_pgw = PS + delta_ps (step_03:193,369), hus_pgw from e (:262-266,370)
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime, long long ncol,
+                                                           const T *__restrict__ PS, const double *__restrict__ delta_ps,
+                                                           const T *__restrict__ evap, T *__restrict__ ps_out,
+                                                           T *__restrict__ hus_out) {
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    if (g >= ngroups) return;
+    ColIdx ix = col_index(g, V, ncol);
+    long long c2 = ix.t * ncol + ix.c;
+    double ps0[V], dps[V], ps[V];
+    loadv<T, V>(PS + c2, ps0);
+    loadv<double, V>(delta_ps + c2, dps);
+#pragma unroll
+    for (int v = 0; v < V; ++v) ps[v] = ps0[v] + dps[v];
+    if (ps_out) storev<T, V>(ps_out + c2, ps);
+    if (hus_out) {
+        const int N = lv.nlev;
+        long long base = ix.t * N * ncol + ix.c;
+#pragma unroll 4
+        for (int l = 0; l < N; ++l) {
+            double e[V], r[V];
+            loadv<T, V>(evap + base + (long long)l * ncol, e);
+            double am = lv.akm[l], bm = lv.bkm[l];
+#pragma unroll
+            for (int v = 0; v < V; ++v) r[v] = e_to_q(e[v], am + ps[v] * bm);
+            storev<T, V>(hus_out + base + (long long)l * ncol, r);
+        }
+    }
+}
+
+// g * dzg (step_03:292-293) into the fp64 state array
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_scale_to_f64(long long n, const T *__restrict__ x, double s,
+                                                        double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = (double)x[i] * s;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_to_f64(long long n, const T *__restrict__ x, double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = (double)x[i];
+}
+
+// =====================================================================================
+// a6  interp_logp_4d, signature-faithful                       functions.py:434-580
+// Source columns (ln p and values) are staged once in LDS, laid out [level][thread] so a
+// wave's read of one level is conflict-free; each target level is then located by the
+// reference's "first s with src[s] == x or src[s] > x" rule.  The scan resumes from the
+// previous hit while targets ascend (all earlier sources are < the previous target <= x,
+// so they cannot match) and restarts from 0 otherwise -> identical selection, O(N+S).
+// =====================================================================================
+template <int MODE>
+__device__ __forceinline__ double interp_pick(int s, int S, double x, const double *sx, const double *sy,
+                                              int stride, bool &extrap) {
+    // s = first index with sx[s] >= x (NaN-safe), S if none
+    int i1, i2;
+    extrap = false;
+    if (s >= S) {                                  // above range            :554-561
+        extrap = true;
+        if (MODE == 1) { i1 = S - 2; i2 = S - 1; } else { i1 = i2 = S - 1; }
+    } else {
+        double xs = sx[s * stride];
+        if (xs == x) { i1 = i2 = s; }              // exact                  :540-543
+        else if (s == 0) {                         // below range            :530-538
+            extrap = true;
+            if (MODE == 1) { i1 = 0; i2 = 1; } else { i1 = i2 = 0; }
+        } else { i1 = s - 1; i2 = s; }             // bracket                :545-548
+    }
+    if (extrap && MODE == 3) return __builtin_nan("");          // :569-570
+    if (i1 == i2) return sy[i1 * stride];                       // :572-573
+    double x1 = sx[i1 * stride], x2 = sx[i2 * stride];
+    double y1 = sy[i1 * stride], y2 = sy[i2 * stride];
+    return y1 + (x - x1) * (y2 - y1) / (x2 - x1);               // :575-578
+}
+
+template <typename T, int MODE, int TPB>
+__global__ __launch_bounds__(TPB) void k_interp_logp(int ntime, int S, int N, long long ncol,
+                                                     const T *__restrict__ var, const T *__restrict__ srcP,
+                                                     const T *__restrict__ trgP, T *__restrict__ out,
+                                                     int logp_in, DevStatus *st) {
+    extern __shared__ double lds[];                 // sx[S][TPB], sy[S][TPB]
+    double *sx = lds + threadIdx.x;
+    double *sy = lds + (size_t)S * TPB + threadIdx.x;
+    long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (flat >= (long long)ntime * ncol) return;    // no barrier in this kernel: columns are private
+    long long t = flat / ncol, c = flat - t * ncol;
+    const T *pv = var + t * S * ncol + c;
+    const T *pp = srcP + t * S * ncol + c;
+    for (int s = 0; s < S; ++s) {
+        sx[s * TPB] = logp_in ? (double)pp[(long long)s * ncol] : log((double)pp[(long long)s * ncol]);   // :470
+        sy[s * TPB] = (double)pv[(long long)s * ncol];
+    }
+    if (sx[(S - 1) * TPB] < sx[0]) { report(st, 10, flat); }     // :500-501
+    const T *pt = trgP + t * N * ncol + c;
+    T *po = out + t * N * ncol + c;
+    double x_first = (double)pt[0], x_last = (double)pt[(long long)(N - 1) * ncol];
+    if (!logp_in) { x_first = log(x_first); x_last = log(x_last); }
+    if (x_last < x_first) { report(st, 11, flat); }              // :502-503
+    int j = 0;
+    double xprev = -__builtin_inf();
+#pragma unroll 4
+    for (int l = 0; l < N; ++l) {
+        double x = (double)pt[(long long)l * ncol];
+        if (!logp_in) x = log(x);                                // :471
+        if (!(x >= xprev)) j = 0;                                // restart (descending or NaN)
+        while (j < S) {
+            double xs = sx[j * TPB];
+            if (xs == x || xs > x) break;
+            ++j;
+        }
+        bool extrap;
+        double y = interp_pick<MODE>(j, S, x, sx, sy, TPB, extrap);
+        if (MODE == 0 && extrap) report(st, 12, flat);           // :564-566
+        po[(long long)l * ncol] = (T)y;
+        xprev = (x == x) ? x : __builtin_inf();                  // after a NaN target restart
+    }
+}
+
+// =====================================================================================
+// a7  time lerp of load_delta                                   functions.py:288-292
+// =====================================================================================
+template <typename T, int V>
+__global__ __launch_bounds__(BLOCK) void k_time_lerp(long long n, const T *__restrict__ vb, const T *__restrict__ va,
+                                                     double x_hi, double x_new, T *__restrict__ out) {
+    long long stride = (long long)gridDim.x * BLOCK;
+    for (long long g = (long long)blockIdx.x * BLOCK + threadIdx.x; g * V < n; g += stride) {
+        double b[V], a[V], r[V];
+        loadv<T, V>(vb + g * V, b);
+        loadv<T, V>(va + g * V, a);
+#pragma unroll
+        for (int v = 0; v < V; ++v) r[v] = (a[v] - b[v]) / x_hi * x_new + b[v];
+        storev<T, V>(out + g * V, r);
+    }
+}
+
+// =====================================================================================
+// a8  vert_interp_delta fused per column                        functions.py:343-431
+// (+ time lerp :288-292, + era + delta step_03:170-173).  The source axis is the 1-D plev
+// table (uniform, passed by value) except for the one level replace_delta_sfc moves to
+// ps_hist, so nothing is staged: ln(plev) is a scalar table, delta values are gathered from
+// the two bracketing records as the scan advances (each source level is read ~once).
+// =====================================================================================
+constexpr int MAX_PLEV = 64;
+struct PlevTable {
+    double p[MAX_PLEV];      // ascending-index order (file order reversed, :383-384)
+    double lnp[MAX_PLEV];
+    double pmax, pmin;
+    int n;
+};
+
+template <typename T>
+struct DeltaSrc {
+    const T *b, *a;          // bracketing records (a may be null)
+    double x_hi, x_new;
+    __device__ __forceinline__ double get(long long off) const {
+        double vb = (double)b[off];
+        if (!a) return vb;                                        // :282-283
+        double va = (double)a[off];
+        return (va - vb) / x_hi * x_new + vb;                     // :288-292 (scipy interp1d linear)
+    }
+};
+
+template <typename T, bool HAS_SFC>
+__global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Levels lv, int ntime, int N, long long ncol,
+                                                             DeltaSrc<T> dsrc, DeltaSrc<T> sfc, DeltaSrc<T> psh,
+                                                             const T *__restrict__ trgP, const T *__restrict__ ps,
+                                                             int check_top, const T *__restrict__ add_to,
+                                                             T *__restrict__ out, DevStatus *st) {
+    __shared__ double s_mint[BLOCK / 64], s_mins[BLOCK / 64];
+    __shared__ int s_nan[BLOCK / 64];
+    // plev / ln(plev) staged in LDS: lanes index them with their own (divergent) scan position
+    __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
+    const int S = pt.n;
+    if (threadIdx.x < MAX_PLEV) {
+        s_p[threadIdx.x] = pt.p[threadIdx.x];
+        s_lnp[threadIdx.x] = pt.lnp[threadIdx.x];
+    }
+    __syncthreads();
+    long long flat = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double min_t = __builtin_inf(), min_s = __builtin_inf();
+    int nanflag = 0;
+    if (flat < (long long)ntime * ncol) {
+        long long t = flat / ncol, c = flat - t * ncol;
+        long long c2 = flat;
+        long long dbase = t * S * ncol + c;      // delta records are (ntime, S, ncol), file order
+        int ksfc = -1;                           // level moved to ps_hist
+        bool fill_below = false;
+        double d_sfc = 0.0, lnps = 0.0, pshv = 0.0;
+        bool bad = false;
+        if (HAS_SFC) {
+            pshv = psh.get(c2);
+            d_sfc = sfc.get(c2);
+            if (pshv > pt.pmax) {                                  // :356-359
+                ksfc = S - 1;
+            } else if (pshv < pt.pmin) {                           // :360-361
+                bad = true;
+            } else {                                               // :362-365
+                for (int i = 0; i < S; ++i) if (pshv > s_p[i]) ksfc = i;
+                if (ksfc < 0) bad = true;                          // np.max of empty argwhere
+                fill_below = true;
+            }
+            if (bad) { report(st, 15, flat); ksfc = -1; }
+            lnps = log(pshv);
+        }
+        auto srcx = [&](int i) -> double { return (HAS_SFC && i == ksfc) ? lnps : s_lnp[i]; };
+        auto srcy = [&](int i) -> double {
+            if (HAS_SFC && ksfc >= 0 && (i == ksfc || (fill_below && i > ksfc))) return d_sfc;
+            return dsrc.get(dbase + (long long)(S - 1 - i) * ncol);
+        };
+        if (check_top) {
+            // np.min(source_P) over this column (:417)
+            for (int i = 0; i < S; ++i) {
+                double p = (HAS_SFC && i == ksfc) ? pshv : s_p[i];
+                if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
+            }
+        }
+        double psv = 0.0;
+        const T *ptg = nullptr;
+        if (trgP) ptg = trgP + t * N * ncol + c; else psv = (double)ps[c2];
+        long long obase = t * N * ncol + c;
+        int j = 0;
+        double xprev = -__builtin_inf();
+        int ci = -2;                 // cached bracket index: values y[ci], y[ci+1]
+        double y_lo = 0.0, y_hi = 0.0;
+        for (int l = 0; l < N; ++l) {
+            double p = ptg ? (double)ptg[(long long)l * ncol] : (lv.akm[l] + psv * lv.bkm[l]);
+            if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
+            double x = log(p);
+            if (!(x >= xprev)) j = 0;
+            while (j < S) {
+                double xs = srcx(j);
+                if (xs == x || xs > x) break;
+                ++j;
+            }
+            double y;
+            if (j >= S) {                                   // above range, constant :558-560
+                y = srcy(S - 1);
+            } else {
+                double xs = srcx(j);
+                if (xs == x) y = srcy(j);                   // exact :540-543
+                else if (j == 0) y = srcy(0);               // below range, constant :534-536
+                else {
+                    if (ci != j - 1) { y_lo = srcy(j - 1); y_hi = srcy(j); ci = j - 1; }
+                    double x1 = srcx(j - 1);
+                    y = y_lo + (x - x1) * (y_hi - y_lo) / (xs - x1);    // :575-578
+                }
+            }
+            if (add_to) y = (double)add_to[obase + (long long)l * ncol] + y;   // step_03:170-173
+            out[obase + (long long)l * ncol] = (T)y;
+            xprev = (x == x) ? x : __builtin_inf();
+        }
+    }
+    if (check_top) {
+        double wt = wave_min(min_t), ws = wave_min(min_s);
+        int wn = nanflag;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wn |= __shfl_xor(wn, off, 64);
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_mint[w] = wt; s_mins[w] = ws; s_nan[w] = wn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mt = s_mint[0], ms = s_mins[0];
+            int nn = s_nan[0];
+            for (int i = 1; i < BLOCK / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
+            // pressures are compared as ordered bit patterns; negative values (unphysical) map to 0
+            if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
+            if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
+            if (nn) atomicOr(&st->nan_seen, nn);
+        }
+    }
+}
+
+// =====================================================================================
+// a10  bilinear regridding (lat then lon)                      functions.py:817-893
+// One thread per output element, lanes along target lon (coalesced writes; the source grid
+// of one field is ~0.6 MB and stays in L2).  slope*(x_new-x_lo)+y_lo as scipy interp1d.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_zonal_mean_rows(long long nfield, int nlat_s, int nlon_s,
+                                                           const T *__restrict__ src, int south_row, int north_row,
+                                                           double *__restrict__ pole /* [nfield][2] */) {
+    // one wave per (field, pole); NaN-skipping mean like xarray .mean(dim=lon) (:836,:841).
+    // Sequential pairwise-free summation order differs from numpy's pairwise sum by O(eps).
+    long long wv = ((long long)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (wv >= nfield * 2) return;
+    long long f = wv >> 1;
+    int which = (int)(wv & 1);
+    int row = which ? north_row : south_row;
+    if (row < 0) return;
+    const T *r = src + (f * nlat_s + row) * nlon_s;
+    double sum = 0.0;
+    long long cnt = 0;
+    for (int i = lane; i < nlon_s; i += 64) {
+        double v = (double)r[i];
+        if (v == v) { sum += v; cnt += 1; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if (lane == 0) pole[f * 2 + which] = cnt > 0 ? sum / (double)cnt : __builtin_nan("");
+}
+
+struct RegridTables {
+    const int *lat_lo, *lat_hi, *lat_oob;
+    const double *lat_dx, *lat_Dx;
+    const int *lon_lo, *lon_hi, *lon_oob;
+    const double *lon_dx, *lon_Dx;
+};
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, int nlon_s, int nlat_t, int nlon_t,
+                                                  const T *__restrict__ src, RegridTables tb,
+                                                  const double *__restrict__ pole, T *__restrict__ out) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;       // target lon
+    int j = blockIdx.y;                             // target lat
+    if (i >= nlon_t) return;
+    int jl = tb.lat_lo[j], jh = tb.lat_hi[j];
+    double ldx = tb.lat_dx[j], lDx = tb.lat_Dx[j];
+    int joob = tb.lat_oob[j];
+    int il = tb.lon_lo[i], ih = tb.lon_hi[i];
+    double odx = tb.lon_dx[i], oDx = tb.lon_Dx[i];
+    int ioob = tb.lon_oob[i];
+    for (long long f = blockIdx.z; f < nfield; f += gridDim.z) {
+        const T *s = src + f * (long long)nlat_s * nlon_s;
+        auto val = [&](int row, int col) -> double {
+            if (row < 0) return pole[f * 2 + 0];
+            if (row >= nlat_s) return pole[f * 2 + 1];
+            return (double)s[(long long)row * nlon_s + col];
+        };
+        double r;
+        if (joob || ioob) {
+            r = __builtin_nan("");
+        } else {
+            double a_lo = val(jl, il), a_hi = val(jh, il);
+            double b_lo = val(jl, ih), b_hi = val(jh, ih);
+            double ya = (a_hi - a_lo) / lDx * ldx + a_lo;      // lat pass at the lower lon  :859
+            double yb = (b_hi - b_lo) / lDx * ldx + b_lo;      // lat pass at the upper lon
+            r = (yb - ya) / oDx * odx + ya;                    // lon pass                    :892
+        }
+        out[(f * nlat_t + j) * (long long)nlon_t + i] = (T)r;
+    }
+}
+
+// =====================================================================================
+// a9  surface riders               step_03_apply_to_era.py:103-146, functions.py:1145-1186
+// =====================================================================================
+constexpr int MAX_SOIL = 16;
+struct SoilTable { double w[MAX_SOIL]; int n; };     // w = exp(-depth/2.8), computed on the host
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_surface_update(int ntime, long long ncol, SoilTable soil,
+                                                          const T *__restrict__ sic, const T *__restrict__ dsic,
+                                                          const T *__restrict__ dtos, const T *__restrict__ dts,
+                                                          const T *__restrict__ land, const T *__restrict__ clim,
+                                                          const T *__restrict__ tskin, const T *__restrict__ tso,
+                                                          T *__restrict__ sic_out, T *__restrict__ comb_out,
+                                                          T *__restrict__ tskin_out, T *__restrict__ tso_out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long n = (long long)ntime * ncol;
+    if (i >= n) return;
+    long long t = i / ncol, c = i - t * ncol;
+    double ice = (double)sic[i] + (double)dsic[i] / 100;             // step_03:105
+    ice = fmin(fmax(ice, 0.0), 1.0);                                  // :106-107 (np.clip keeps NaN)
+    if ((double)sic[i] != (double)sic[i] || (double)dsic[i] != (double)dsic[i]) ice = __builtin_nan("");
+    if (sic_out) sic_out[i] = (T)ice;
+    double tos = (double)dtos[i], ts = (double)dts[i];
+    // land fraction / sea ice of time step 0 (step_03:121-122 .isel(time=0))
+    double lf = (double)land[c];
+    double ice0 = ice;
+    if (t != 0) {
+        double i0 = (double)sic[c] + (double)dsic[c] / 100;
+        i0 = fmin(fmax(i0, 0.0), 1.0);
+        if ((double)sic[c] != (double)sic[c] || (double)dsic[c] != (double)dsic[c]) i0 = __builtin_nan("");
+        ice0 = i0;
+    }
+    double comb = ts;                                                 // functions.py:1180-1181
+    if (ice0 == ice0 && tos == tos) {                                 // :1173
+        double fr = fmin(fmax(ice0 + lf, 0.0), 1.0);                  // :1183
+        comb = fr * ts + (1 - fr) * tos;                              // :1184
+    }
+    if (comb_out) comb_out[i] = (T)comb;
+    if (tskin_out) tskin_out[i] = (T)((double)tskin[i] + comb);       // step_03:124
+    if (tso_out) {
+        double cl = (double)clim[c];                                  // annual mean ts delta :134-136
+#pragma unroll
+        for (int s = 0; s < MAX_SOIL; ++s) {
+            if (s < soil.n) {
+                long long o = (t * soil.n + s) * ncol + c;
+                tso_out[o] = (T)((double)tso[o] + (cl + soil.w[s] * (comb - cl)));   // :139-144
+            }
+        }
+    }
+}
+
+// replace_delta_sfc (functions.py:343-366) on many ascending-pressure columns: source_P is the
+// broadcast 1-D table, delta (ntime, S, ncol) ascending order; outputs the modified columns.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_replace_delta_sfc(PlevTable pt, int ntime, long long ncol,
+                                                             const T *__restrict__ delta, const T *__restrict__ dsfc,
+                                                             const T *__restrict__ pshist, T *__restrict__ outP,
+                                                             T *__restrict__ outD, DevStatus *st) {
+    __shared__ double s_p[MAX_PLEV];
+    const int S = pt.n;
+    if (threadIdx.x < MAX_PLEV) s_p[threadIdx.x] = pt.p[threadIdx.x];
+    __syncthreads();
+    long long flat = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (flat >= (long long)ntime * ncol) return;
+    long long t = flat / ncol, c = flat - t * ncol;
+    long long base = t * S * ncol + c;
+    double ps = (double)pshist[flat], ds = (double)dsfc[flat];
+    int k = -1;
+    bool fill = false;
+    if (ps > pt.pmax) k = S - 1;                                   // :356-359
+    else if (ps < pt.pmin) { report(st, 15, flat); }               // :360-361
+    else {                                                         // :362-365
+        for (int i = 0; i < S; ++i) if (ps > s_p[i]) k = i;
+        if (k < 0) report(st, 15, flat);
+        fill = true;
+    }
+    for (int i = 0; i < S; ++i) {
+        double P = s_p[i], D = (double)delta[base + (long long)i * ncol];
+        if (k >= 0) {
+            if (i == k) { P = ps; D = ds; }
+            else if (fill && i > k) D = ds;
+        }
+        outP[base + (long long)i * ncol] = (T)P;
+        outD[base + (long long)i * ncol] = (T)D;
+    }
+}
+
+// integrate_tos (functions.py:1145-1186), flat over n
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_integrate_tos(long long n, const T *__restrict__ tos, const T *__restrict__ ts,
+                                                         const T *__restrict__ land, const T *__restrict__ ice,
+                                                         T *__restrict__ out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double o = (double)tos[i], s = (double)ts[i], ic = (double)ice[i];
+    double r = s;                                                   // :1180-1181
+    if (ic == ic && o == o) {                                       // :1173
+        double fr = fmin(fmax(ic + (double)land[i], 0.0), 1.0);     // :1183 (np.clip propagates NaN)
+        if ((double)land[i] != (double)land[i]) fr = __builtin_nan("");
+        r = fr * s + (1 - fr) * o;                                  // :1184
+    }
+    out[i] = (T)r;
+}
+
+// ln() of a small table with the device log (so table entries and per-column logs come from
+// the same implementation)
+__global__ void k_log_table(int n, const double *in, double *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log(in[i]);
+}
+
+}  // namespace pgw

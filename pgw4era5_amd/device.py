@@ -1,0 +1,215 @@
+"""
+Device context and device-resident arrays for the HIP path.
+
+`Context` wraps one `pgw_ctx` (one HIP device + stream); `DeviceArray` is a shape/dtype-tagged
+device buffer.  Arrays stay in HBM between calls (288 GB per MI355X: a whole 0.25 deg L137 file,
+its PGW state and all twelve months of every delta fit many times over), host<->device copies
+happen only at the edges (`Context.to_device`, `DeviceArray.numpy`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+_DTYPE_TAG = {np.dtype('float32'): _lib.PGW_F32, np.dtype('float64'): _lib.PGW_F64}
+
+
+def dtype_tag(dtype):
+    try:
+        return _DTYPE_TAG[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError('field arrays must be float32 or float64, got %s' % dtype)
+
+
+class DeviceArray:
+    """A C-order array in device memory owned by a Context."""
+
+    __slots__ = ('ctx', 'ptr', 'shape', 'dtype', 'nbytes', '_owner', '__weakref__')
+
+    def __init__(self, ctx, shape, dtype, ptr=None, owner=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._owner = owner
+        if ptr is None:
+            p = C.c_void_p()
+            ctx._check(ctx.lib.pgw_malloc(ctx.handle, self.nbytes, C.byref(p)))
+            self.ptr = p.value
+            self._owner = self
+            ctx._live += self.nbytes
+        else:
+            self.ptr = ptr
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            self.ctx._check(self.ctx.lib.pgw_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
+            self.ctx.sync()
+        return out
+
+    def copy_from(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.shape != self.shape:
+            raise ValueError('shape mismatch %s vs %s' % (host.shape, self.shape))
+        if self.nbytes:
+            self.ctx._check(self.ctx.lib.pgw_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes))
+            self.ctx.sync()          # pageable source: keep it alive until the copy is done
+        return self
+
+    def view(self, shape):
+        """Reshaped alias of the same buffer."""
+        shape = tuple(int(s) for s in shape)
+        if int(np.prod(shape, dtype=np.int64)) != self.size:
+            raise ValueError('cannot view %s as %s' % (self.shape, shape))
+        return DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr, owner=self._owner)
+
+    def slab(self, index):
+        """Alias of sub-array [index] along axis 0 (contiguous)."""
+        sub = self.shape[1:]
+        n = int(np.prod(sub, dtype=np.int64)) * self.dtype.itemsize
+        if not (0 <= index < self.shape[0]):
+            raise IndexError(index)
+        return DeviceArray(self.ctx, sub, self.dtype, ptr=self.ptr + index * n, owner=self._owner)
+
+    def free(self):
+        if self._owner is self and self.ptr:
+            self.ctx.lib.pgw_free(self.ctx.handle, self.ptr)
+            self.ctx._live -= self.nbytes
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self._owner is self and self.ptr and self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+    # duck-typing used by the functions.py mirror
+    @property
+    def values(self):
+        return self.numpy()
+
+
+class Context:
+    """One HIP device + stream (`pgw_ctx`)."""
+
+    def __init__(self, device=None):
+        self.lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+        n = C.c_int(0)
+        self.lib.pgw_device_count(C.byref(n))
+        if n.value <= 0:
+            raise _lib.PGWHipError('no HIP device visible: pgw4era5_amd needs an MI355X (no CPU fallback)')
+        h = C.c_void_p()
+        rc = self.lib.pgw_ctx_create(int(device) % n.value, C.byref(h))
+        if rc != 0:
+            raise _lib.PGWHipError('pgw_ctx_create(device=%d) failed with status %d' % (device, rc))
+        self.handle = h
+        self.device = int(device) % n.value
+        self._live = 0
+        self._levels_key = None
+
+    def _check(self, rc):
+        _lib.check(self.handle, rc)
+
+    def close(self):
+        if self.handle:
+            self.lib.pgw_ctx_destroy(self.handle)
+            self.handle = None
+
+    def sync(self):
+        self._check(self.lib.pgw_sync(self.handle))
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.pgw_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def mem_info(self):
+        f, t = C.c_size_t(), C.c_size_t()
+        self._check(self.lib.pgw_mem_info(self.handle, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    # ---- arrays --------------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        a = DeviceArray(self, shape, dtype)
+        self._check(self.lib.pgw_memset(self.handle, a.ptr, 0, a.nbytes))
+        return a
+
+    def to_device(self, host, dtype=None):
+        host = np.asarray(host)
+        if dtype is None:
+            dtype = host.dtype if host.dtype in (np.float32, np.float64) else np.float64
+        a = DeviceArray(self, host.shape, dtype)
+        return a.copy_from(host)
+
+    # ---- profiling -----------------------------------------------------------------------
+    def profile(self, on=True):
+        self._check(self.lib.pgw_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.pgw_profile_reset(self.handle))
+
+    def profile_get(self, kernel):
+        n, ms = C.c_longlong(), C.c_double()
+        self._check(self.lib.pgw_profile_get(self.handle, _lib.KERNEL_IDS[kernel], C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def timer_start(self):
+        self._check(self.lib.pgw_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        self._check(self.lib.pgw_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # ---- vertical grid -------------------------------------------------------------------
+    def set_levels(self, ak, bk, akm=None, bkm=None):
+        ak = np.ascontiguousarray(ak, dtype=np.float64)
+        bk = np.ascontiguousarray(bk, dtype=np.float64)
+        key = (ak.tobytes(), bk.tobytes(),
+               None if akm is None else np.asarray(akm, dtype=np.float64).tobytes(),
+               None if bkm is None else np.asarray(bkm, dtype=np.float64).tobytes())
+        if key == self._levels_key:
+            return
+        dp = C.POINTER(C.c_double)
+        if akm is not None:
+            akm = np.ascontiguousarray(akm, dtype=np.float64)
+            bkm = np.ascontiguousarray(bkm, dtype=np.float64)
+            pm, pb = akm.ctypes.data_as(dp), bkm.ctypes.data_as(dp)
+        else:
+            pm = pb = None
+        self._check(self.lib.pgw_set_levels(self.handle, len(ak) - 1, ak.ctypes.data_as(dp),
+                                            bk.ctypes.data_as(dp), pm, pb))
+        self._levels_key = key
+        self.nlev = len(ak) - 1
+
+
+_default = None
+
+
+def default_context():
+    """Process-wide context (device = LOCAL_RANK, one process per GPU)."""
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default
+
+
+def ptr(a):
+    return None if a is None else a.ptr

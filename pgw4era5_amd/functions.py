@@ -1,0 +1,425 @@
+"""
+Host-side mirror of the reference's `functions.py` numerical API, backed by the HIP library.
+
+Every function keeps the reference's name, argument order and error behaviour
+(reference functions.py line ranges are cited per function) and runs on the GPU through the
+C-ABI in include/pgw_hip.h.  There is no CPU implementation behind these names.
+
+Accepted array kinds, everywhere a field is expected:
+  * `numpy.ndarray` (float32/float64)      -> copied to the device, result returned as ndarray
+  * `pgw4era5_amd.device.DeviceArray`      -> used in place, result stays on the device
+  * labelled arrays (`pgw4era5_amd.ncio.Field`, or any object with `.values`, `.dims`,
+    `.coords`)                             -> like ndarray, result re-wrapped with the labels
+4-D fields are C-order `(time, level, lat, lon)`.
+"""
+import ctypes as C
+import datetime as _dt
+import os
+
+import numpy as np
+
+from . import _lib
+from .constants import CON_G, CON_RD, CON_MW_MD   # noqa: F401  (re-exported like the reference)
+from .device import DeviceArray, default_context, dtype_tag, ptr
+from .settings import (                      # noqa: F401
+    i_debug, i_use_xesmf_regridding, file_name_bases,
+    TIME_ERA, LEV_ERA, HLEV_ERA, LON_ERA, LAT_ERA,
+    TIME_GCM, PLEV_GCM, LON_GCM, LAT_GCM,
+)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+# ------------------------------------------------------------------------------- helpers
+def _is_labelled(x):
+    return hasattr(x, 'values') and hasattr(x, 'dims') and not isinstance(x, DeviceArray)
+
+
+def _raw(x):
+    """ndarray / DeviceArray behind any accepted input."""
+    if isinstance(x, DeviceArray):
+        return x
+    if _is_labelled(x):
+        return np.asarray(x.values)
+    return np.asarray(x)
+
+
+def _common_dtype(*xs):
+    for x in xs:
+        if x is None:
+            continue
+        r = _raw(x)
+        if r.dtype == np.float64:
+            return np.dtype('float64')
+        if r.dtype not in (np.dtype('float32'),):
+            if not isinstance(r, DeviceArray) and r.dtype.kind in 'iu':
+                return np.dtype('float64')
+    return np.dtype('float32')
+
+
+def _dev(ctx, x, dtype, shape=None):
+    """Device array of `x` in `dtype` (no copy if it already is one of that dtype)."""
+    if x is None:
+        return None
+    r = _raw(x)
+    if isinstance(r, DeviceArray):
+        if r.dtype != dtype:
+            raise TypeError('device arrays of mixed dtype: got %s, expected %s' % (r.dtype, dtype))
+        return r if shape is None else r.view(shape)
+    a = np.ascontiguousarray(r, dtype=dtype)
+    if shape is not None:
+        a = a.reshape(shape)
+    return ctx.to_device(a, dtype)
+
+
+def _out(ctx, dev, like):
+    """Return `dev` in the kind of `like`."""
+    if isinstance(like, DeviceArray):
+        return dev
+    host = dev.numpy()
+    if _is_labelled(like) and hasattr(like, 'like'):
+        return like.like(host)
+    return host
+
+
+def _shape4(x):
+    s = _raw(x).shape
+    if len(s) != 4:
+        raise ValueError('expected a 4-D (time, level, lat, lon) array, got shape %s' % (s,))
+    return s
+
+
+# ------------------------------------------------------------------------------- humidity
+def specific_to_relative_humidity(hus, pa, ta):
+    """RH [%] from specific humidity (IFS 7.92/7.93).  reference functions.py:107-116."""
+    ctx = default_context()
+    dt = _common_dtype(hus, pa, ta)
+    shp = _raw(hus).shape
+    dh, dp_, dt_ = _dev(ctx, hus, dt), _dev(ctx, np.broadcast_to(_raw(pa), shp) if not isinstance(_raw(pa), DeviceArray) else pa, dt), _dev(ctx, ta, dt)
+    out = ctx.empty(shp, dt)
+    ctx._check(ctx.lib.pgw_specific_to_relative_humidity(ctx.handle, dtype_tag(dt), out.size, dh.ptr, dp_.ptr, dt_.ptr, out.ptr))
+    return _out(ctx, out, hus)
+
+
+def relative_to_specific_humidity(hur, pa, ta):
+    """Specific humidity from RH [%].  reference functions.py:118-125."""
+    ctx = default_context()
+    dt = _common_dtype(hur, pa, ta)
+    shp = _raw(hur).shape
+    dh, dp_, dt_ = _dev(ctx, hur, dt), _dev(ctx, np.broadcast_to(_raw(pa), shp) if not isinstance(_raw(pa), DeviceArray) else pa, dt), _dev(ctx, ta, dt)
+    out = ctx.empty(shp, dt)
+    ctx._check(ctx.lib.pgw_relative_to_specific_humidity(ctx.handle, dtype_tag(dt), out.size, dh.ptr, dp_.ptr, dt_.ptr, out.ptr))
+    return _out(ctx, out, hur)
+
+
+# ------------------------------------------------------------------------------- pressure
+def hybrid_pressure(ak, bk, ps, akm=None, bkm=None):
+    """pa_hl = ak + ps*bk, pa = akm + ps*bkm  (reference step_03_apply_to_era.py:64-88,196-199;
+    this is what BASELINE.json calls "integ_pressure").  ps (time, lat, lon) -> (pa_hl, pa)."""
+    ctx = default_context()
+    ctx.set_levels(ak, bk, akm, bkm)
+    dt = _common_dtype(ps)
+    s = _raw(ps).shape
+    if len(s) != 3:
+        raise ValueError('ps must be (time, lat, lon)')
+    nt, ncol, n = s[0], s[1] * s[2], ctx.nlev
+    dps = _dev(ctx, ps, dt)
+    pa_hl = ctx.empty((nt, n + 1, s[1], s[2]), dt)
+    pa = ctx.empty((nt, n, s[1], s[2]), dt)
+    ctx._check(ctx.lib.pgw_pressure_levels(ctx.handle, dtype_tag(dt), nt, ncol, dps.ptr, pa_hl.ptr, pa.ptr))
+    if isinstance(ps, DeviceArray):
+        return pa_hl, pa
+    return pa_hl.numpy(), pa.numpy()
+
+
+# ------------------------------------------------------------------------------- integ_geopot
+def integ_geopot(pa_hl, zgs, ta, hus, level1, p_ref, full_column=True):
+    """Geopotential at p_ref by hydrostatic integration from the surface.
+    reference functions.py:128-189.  `level1` = half-level labels (its length must be N+1).
+    p_ref: scalar or (time, lat, lon) field.  Returns (time, lat, lon)."""
+    ctx = default_context()
+    s = _shape4(pa_hl)
+    st = _shape4(ta)
+    if len(level1) != s[1] or st[1] != s[1] - 1 or _shape4(hus) != st:
+        raise ValueError('level dimensions are inconsistent')
+    dt = _common_dtype(pa_hl, zgs, ta, hus)
+    nt, n, ncol = s[0], st[1], s[2] * s[3]
+    d_p, d_z, d_t, d_q = _dev(ctx, pa_hl, dt), _dev(ctx, zgs, dt, (nt, s[2], s[3])), _dev(ctx, ta, dt), _dev(ctx, hus, dt)
+    pref_field = None
+    pref_scalar = 0.0
+    pr = _raw(p_ref) if not np.isscalar(p_ref) else None
+    if pr is not None and (isinstance(pr, DeviceArray) or pr.ndim > 0):
+        pref_field = _dev(ctx, p_ref, dt, (nt, s[2], s[3]))
+    else:
+        pref_scalar = float(p_ref)
+    out = ctx.empty((nt, s[2], s[3]), dt)
+    ctx._check(ctx.lib.pgw_integ_geopot(ctx.handle, dtype_tag(dt), nt, n, ncol, d_p.ptr, d_z.ptr, d_t.ptr, d_q.ptr,
+                                        pref_scalar, ptr(pref_field), out.ptr, 1 if full_column else 0))
+    return _out(ctx, out, zgs)
+
+
+# ------------------------------------------------------------------------------- interpolation
+def _check_extrapolate(extrapolate):
+    if extrapolate not in _lib.EXTRAP:
+        raise ValueError('Invalid input value for "extrapolate"')
+    return _lib.EXTRAP[extrapolate]
+
+
+def interp_logp_4d(var, source_P, targ_P, extrapolate='off', time_key=None, lat_key=None, lon_key=None):
+    """Column-wise linear interpolation in ln(p).  reference functions.py:434-477.
+    var, source_P (time, S, lat, lon); targ_P (time, N, lat, lon) -> (time, N, lat, lon)."""
+    mode = _check_extrapolate(extrapolate)
+    sv, ss, st = _shape4(var), _shape4(source_P), _shape4(targ_P)
+    if (sv[0] != ss[0]) or (sv[0] != st[0]):
+        raise ValueError('Time dimension of input files is inconsistent!')
+    if (sv[2] != ss[2]) or (sv[2] != st[2]):
+        raise ValueError('Lat dimension of input files is inconsistent!')
+    if (sv[3] != ss[3]) or (sv[3] != st[3]):
+        raise ValueError('Lon dimension of input files is inconsistent!')
+    if sv[1] != ss[1]:
+        raise ValueError('Level dimension of var and source_P is inconsistent!')
+    ctx = default_context()
+    dt = _common_dtype(var, source_P, targ_P)
+    d_v, d_s, d_t = _dev(ctx, var, dt), _dev(ctx, source_P, dt), _dev(ctx, targ_P, dt)
+    out = ctx.empty(st, dt)
+    ctx._check(ctx.lib.pgw_interp_logp_4d(ctx.handle, dtype_tag(dt), st[0], sv[1], st[1], st[2] * st[3],
+                                          d_v.ptr, d_s.ptr, d_t.ptr, mode, 0, out.ptr))
+    return _out(ctx, out, targ_P)
+
+
+def interp_1d_for_timelatlon(orig_array, src_p, targ_p, interp_array, ntime, nlat, nlon, extrapolate):
+    """reference functions.py:479-508: inputs already hold ln(p); fills `interp_array` in place."""
+    mode = _check_extrapolate(extrapolate)
+    ctx = default_context()
+    dt = np.dtype('float64')
+    d_v, d_s, d_t = _dev(ctx, orig_array, dt), _dev(ctx, src_p, dt), _dev(ctx, targ_p, dt)
+    out = ctx.empty(d_t.shape, dt)
+    ctx._check(ctx.lib.pgw_interp_logp_4d(ctx.handle, dtype_tag(dt), ntime, d_s.shape[1], d_t.shape[1], nlat * nlon,
+                                          d_v.ptr, d_s.ptr, d_t.ptr, mode, 1, out.ptr))
+    interp_array[...] = out.numpy()
+
+
+def interp_extrap_1d(src_x, src_y, targ_x, extrapolate):
+    """reference functions.py:511-580 for one column (abscissae as given, e.g. ln p)."""
+    mode = _check_extrapolate(extrapolate)
+    ctx = default_context()
+    dt = np.dtype('float64')
+    S, N = len(src_x), len(targ_x)
+    d_s = _dev(ctx, np.asarray(src_x, dtype=dt).reshape(1, S, 1, 1), dt)
+    d_v = _dev(ctx, np.asarray(src_y, dtype=dt).reshape(1, S, 1, 1), dt)
+    d_t = _dev(ctx, np.asarray(targ_x, dtype=dt).reshape(1, N, 1, 1), dt)
+    out = ctx.empty((1, N, 1, 1), dt)
+    rc = ctx.lib.pgw_interp_logp_4d(ctx.handle, dtype_tag(dt), 1, S, N, 1, d_v.ptr, d_s.ptr, d_t.ptr, mode, 1, out.ptr)
+    # the 1-D function has no ascending pre-check (that lives in interp_1d_for_timelatlon)
+    if rc in (10, 11):
+        rc = 0
+    ctx._check(rc)
+    return out.numpy().reshape(N)
+
+
+# ------------------------------------------------------------------------------- deltas
+def time_lerp(v_before, v_after, x_hi, x_new):
+    """(v_after - v_before)/x_hi * x_new + v_before: the arithmetic under load_delta's
+    `.interp(time=...)` (reference functions.py:288-292; scipy interp1d linear)."""
+    ctx = default_context()
+    dt = _common_dtype(v_before, v_after)
+    d_b, d_a = _dev(ctx, v_before, dt), _dev(ctx, v_after, dt)
+    out = ctx.empty(d_b.shape, dt)
+    ctx._check(ctx.lib.pgw_time_lerp(ctx.handle, dtype_tag(dt), out.size, d_b.ptr, d_a.ptr, float(x_hi), float(x_new), out.ptr))
+    return _out(ctx, out, v_before)
+
+
+def replace_delta_sfc(source_P, ps_hist, delta, delta_sfc):
+    """reference functions.py:343-366 for one ascending-pressure column."""
+    ctx = default_context()
+    dt = np.dtype('float64')
+    P = np.ascontiguousarray(source_P, dtype=dt)
+    S = len(P)
+    d_d = _dev(ctx, np.asarray(delta, dtype=dt).reshape(1, S, 1), dt)
+    d_s = _dev(ctx, np.asarray([[delta_sfc]], dtype=dt), dt)
+    d_p = _dev(ctx, np.asarray([[ps_hist]], dtype=dt), dt)
+    oP, oD = ctx.empty((1, S, 1), dt), ctx.empty((1, S, 1), dt)
+    ctx._check(ctx.lib.pgw_replace_delta_sfc(ctx.handle, dtype_tag(dt), 1, S, 1, P.ctypes.data_as(_dp),
+                                             d_d.ptr, d_s.ptr, d_p.ptr, oP.ptr, oD.ptr))
+    return oP.numpy().reshape(S), oD.numpy().reshape(S)
+
+
+def _plev_of(delta, plev):
+    if plev is not None:
+        return np.ascontiguousarray(plev, dtype=np.float64)
+    if _is_labelled(delta) and PLEV_GCM in getattr(delta, 'coords', {}):
+        return np.ascontiguousarray(delta.coords[PLEV_GCM], dtype=np.float64)
+    raise ValueError('vert_interp_delta needs the plev coordinate (labelled delta or plev=...)')
+
+
+def vert_interp_delta(delta, target_P, delta_sfc=None, ps_hist=None, ignore_top_pressure_error=False,
+                      plev=None, add_to=None, _bracket=None):
+    """Vertical interpolation of a climate delta onto model levels, with the surface delta
+    inserted at the HIST surface pressure.  reference functions.py:369-431 (+ :343-366).
+    delta (time, plev, lat, lon) in the file's plev order (reversed inside like :383-384);
+    target_P (time, N, lat, lon); delta_sfc, ps_hist (time, lat, lon) or None."""
+    ctx = default_context()
+    pl = _plev_of(delta, plev)
+    sd, st = _shape4(delta), _shape4(target_P)
+    if sd[0] != st[0] or sd[2:] != st[2:]:
+        raise ValueError()
+    if (delta_sfc is None) != (ps_hist is None):
+        raise ValueError('delta_sfc and ps_hist must be given together')
+    dt = _common_dtype(delta, target_P, delta_sfc, ps_hist, add_to)
+    nt, S, ncol, N = sd[0], sd[1], sd[2] * sd[3], st[1]
+    d_d, d_t = _dev(ctx, delta, dt), _dev(ctx, target_P, dt)
+    d_s = _dev(ctx, delta_sfc, dt, (nt, sd[2], sd[3])) if delta_sfc is not None else None
+    d_p = _dev(ctx, ps_hist, dt, (nt, sd[2], sd[3])) if ps_hist is not None else None
+    d_add = _dev(ctx, add_to, dt) if add_to is not None else None
+    out = ctx.empty(st, dt)
+    ctx._check(ctx.lib.pgw_vert_interp_delta(
+        ctx.handle, dtype_tag(dt), nt, S, N, ncol, pl.ctypes.data_as(_dp),
+        d_d.ptr, None, 0.0, 0.0, ptr(d_s), None, ptr(d_p), None,
+        d_t.ptr, None, 1 if ignore_top_pressure_error else 0, ptr(d_add), out.ptr))
+    return _out(ctx, out, target_P)
+
+
+def determine_p_ref(p_min_era, p_min_pgw, p_ref_opts, p_ref_last=None):
+    """reference functions.py:583-598 (scalar control logic; host side like the reference)."""
+    for p in p_ref_opts:
+        if (p_min_era > p) & (p_min_pgw > p):
+            if p_ref_last is None:
+                return p
+            return min(p, p_ref_last)
+
+
+def integrate_tos(tos_field, ts_field, land_frac, ice_frac):
+    """Blend SST and skin-temperature deltas by land + sea-ice fraction.
+    reference functions.py:1145-1186."""
+    ctx = default_context()
+    dt = _common_dtype(tos_field, ts_field, land_frac, ice_frac)
+    shp = _raw(tos_field).shape
+    d = [_dev(ctx, x, dt) for x in (tos_field, ts_field, land_frac, ice_frac)]
+    out = ctx.empty(shp, dt)
+    ctx._check(ctx.lib.pgw_integrate_tos(ctx.handle, dtype_tag(dt), out.size, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, out.ptr))
+    return _out(ctx, out, tos_field)
+
+
+# ------------------------------------------------------------------------------- ps loop
+def adjust_ps_loop(ak, bk, PS, FIS, T, QV, ta_pgw, hur_pgw, dzg_pref, akm=None, bkm=None,
+                   p_ref=None, adj_factor=None, thresh=None, max_n_iter=None, want_hus=True):
+    """The iterative surface-pressure adjustment, reference step_03_apply_to_era.py:182-319
+    (fixed p_ref).  Returns dict(ps_pgw, hus_pgw, n_iter, max_err).  Raises the reference's
+    ValueError on non-convergence."""
+    from . import settings as S
+    p_ref = S.p_ref_inp if p_ref is None else p_ref
+    adj_factor = S.adj_factor if adj_factor is None else adj_factor
+    thresh = S.thresh_phi_ref_max_error if thresh is None else thresh
+    max_n_iter = S.max_n_iter if max_n_iter is None else max_n_iter
+    ctx = default_context()
+    ctx.set_levels(ak, bk, akm, bkm)
+    s = _shape4(ta_pgw)
+    dt = _common_dtype(PS, FIS, T, QV, ta_pgw, hur_pgw, dzg_pref)
+    nt, ncol = s[0], s[2] * s[3]
+    s3 = (nt, s[2], s[3])
+    d = dict(PS=_dev(ctx, PS, dt, s3), FIS=_dev(ctx, FIS, dt, s3), T=_dev(ctx, T, dt), QV=_dev(ctx, QV, dt),
+             ta=_dev(ctx, ta_pgw, dt), hur=_dev(ctx, hur_pgw, dt), dzg=_dev(ctx, dzg_pref, dt, s3))
+    ps_out = ctx.empty(s3, dt)
+    hus_out = ctx.empty(s, dt) if want_hus else None
+    n_iter = C.c_int(0)
+    hist = (C.c_double * int(max_n_iter))()
+    rc = ctx.lib.pgw_adjust_ps_loop(ctx.handle, dtype_tag(dt), nt, ncol, d['PS'].ptr, d['FIS'].ptr, d['T'].ptr,
+                                    d['QV'].ptr, d['ta'].ptr, d['hur'].ptr, d['dzg'].ptr, float(p_ref),
+                                    float(adj_factor), float(thresh), int(max_n_iter), ps_out.ptr, ptr(hus_out),
+                                    C.byref(n_iter), hist)
+    ctx._check(rc)
+    res = dict(n_iter=n_iter.value, max_err=[hist[i] for i in range(n_iter.value)],
+               levels_touched=int(ctx.lib.pgw_last_levels_touched(ctx.handle)))
+    if isinstance(ta_pgw, DeviceArray):
+        res.update(ps_pgw=ps_out, hus_pgw=hus_out)
+    else:
+        res.update(ps_pgw=ps_out.numpy(), hus_pgw=hus_out.numpy() if want_hus else None)
+    return res
+
+
+# ------------------------------------------------------------------------------- regridding
+def regrid_tables(src_lat, src_lon, targ_lat, targ_lon):
+    """Index/weight tables for the separable lat-then-lon linear interpolation of
+    regrid_lat_lon's xarray branch (reference functions.py:774-789, 817-893), including its
+    pole rows, periodic +-360 extension and scipy-interp1d index rule (searchsorted-left,
+    clip to [1, n-1]).  Raises the reference's ValueErrors for uncovered targets."""
+    src_lat = np.asarray(src_lat, dtype=np.float64)
+    src_lon = np.asarray(src_lon, dtype=np.float64)
+    targ_lat = np.asarray(targ_lat, dtype=np.float64)
+    targ_lon = np.asarray(targ_lon, dtype=np.float64)
+    nlat_s, nlon_s = len(src_lat), len(src_lon)
+    dlon = np.median(np.diff(src_lon))                          # :778
+    dlat = np.median(np.diff(src_lat))                          # :779 (before the flip)
+    periodic = (dlon + np.max(src_lon) - np.min(src_lon)) >= 359.9     # :780-789
+    rows = np.arange(nlat_s)
+    lat = src_lat
+    if lat[0] > lat[-1]:                                        # :822-829
+        lat = lat[::-1]
+        rows = rows[::-1]
+    south_row = north_row = -1
+    if np.max(targ_lat) + dlat > 89.9:                          # :833-837
+        north_row = int(rows[-1])
+        lat = np.concatenate([lat, [90.0]])
+        rows = np.concatenate([rows, [nlat_s]])
+    if np.min(targ_lat) - dlat < -89.9:                         # :838-842
+        south_row = int(rows[0])
+        lat = np.concatenate([[-90.0], lat])
+        rows = np.concatenate([[-1], rows])
+    if (np.max(targ_lat) > np.max(lat)) | (np.min(targ_lat) < np.min(lat)):      # :845-856
+        raise ValueError('ERA5 dataset extends further North or South than GCM dataset!. Perhaps consider '
+                         'using ERA5 on a subdomain only if global coverage is not required?')
+    order = np.argsort(lat, kind='stable')                      # xarray sorts before interp
+    lat, rows = lat[order], rows[order]
+    idx = np.searchsorted(lat, targ_lat).clip(1, len(lat) - 1)
+    lat_lo, lat_hi = rows[idx - 1].astype(np.int32), rows[idx].astype(np.int32)
+    lat_dx = targ_lat - lat[idx - 1]
+    lat_Dx = lat[idx] - lat[idx - 1]
+    lat_oob = ((targ_lat < lat[0]) | (targ_lat > lat[-1])).astype(np.int32)
+
+    lon = src_lon
+    cols = np.arange(nlon_s)
+    if periodic:                                                # :866-874
+        if np.max(targ_lon) > np.max(lon):
+            lon = np.concatenate([lon, src_lon + 360])
+            cols = np.concatenate([cols, np.arange(nlon_s)])
+        if np.min(targ_lon) < np.min(lon):
+            lon = np.concatenate([lon - 360, lon])
+            cols = np.concatenate([cols, cols])
+    if (np.max(targ_lon) > np.max(lon)) | (np.min(targ_lon) < np.min(lon)):      # :877-888
+        raise ValueError('ERA5 dataset extends further East or West than GCM dataset!. Perhaps consider '
+                         'using ERA5 on a subdomain only if global coverage is not required?')
+    order = np.argsort(lon, kind='stable')
+    lon, cols = lon[order], cols[order]
+    idx = np.searchsorted(lon, targ_lon).clip(1, len(lon) - 1)
+    lon_lo, lon_hi = cols[idx - 1].astype(np.int32), cols[idx].astype(np.int32)
+    lon_dx = targ_lon - lon[idx - 1]
+    lon_Dx = lon[idx] - lon[idx - 1]
+    lon_oob = ((targ_lon < lon[0]) | (targ_lon > lon[-1])).astype(np.int32)
+    return dict(lat_lo=lat_lo, lat_hi=lat_hi, lat_dx=lat_dx, lat_Dx=lat_Dx, lat_oob=lat_oob,
+                lon_lo=lon_lo, lon_hi=lon_hi, lon_dx=lon_dx, lon_Dx=lon_Dx, lon_oob=lon_oob,
+                south_row=south_row, north_row=north_row, periodic=bool(periodic))
+
+
+def regrid_field(field, src_lat, src_lon, targ_lat, targ_lon):
+    """Bilinear (lat, then lon) regridding of field (..., nlat_s, nlon_s) on the GPU."""
+    ctx = default_context()
+    tb = regrid_tables(src_lat, src_lon, targ_lat, targ_lon)
+    r = _raw(field)
+    shp = r.shape
+    dt = _common_dtype(field)
+    nlat_s, nlon_s = shp[-2], shp[-1]
+    if nlat_s != len(src_lat) or nlon_s != len(src_lon):
+        raise ValueError('field shape does not match the source coordinates')
+    nfield = int(np.prod(shp[:-2], dtype=np.int64)) if len(shp) > 2 else 1
+    d_src = _dev(ctx, field, dt)
+    out = ctx.empty(shp[:-2] + (len(targ_lat), len(targ_lon)), dt)
+    c = {k: np.ascontiguousarray(v) for k, v in tb.items() if isinstance(v, np.ndarray)}
+    ctx._check(ctx.lib.pgw_regrid_bilinear(
+        ctx.handle, dtype_tag(dt), nfield, nlat_s, nlon_s, len(targ_lat), len(targ_lon), d_src.ptr,
+        c['lat_lo'].ctypes.data_as(_ip), c['lat_hi'].ctypes.data_as(_ip), c['lat_dx'].ctypes.data_as(_dp),
+        c['lat_Dx'].ctypes.data_as(_dp), c['lat_oob'].ctypes.data_as(_ip),
+        c['lon_lo'].ctypes.data_as(_ip), c['lon_hi'].ctypes.data_as(_ip), c['lon_dx'].ctypes.data_as(_dp),
+        c['lon_Dx'].ctypes.data_as(_dp), c['lon_oob'].ctypes.data_as(_ip),
+        tb['south_row'], tb['north_row'], out.ptr))
+    return _out(ctx, out, field)

@@ -20,16 +20,17 @@ PLEV19 = np.array([100000., 92500., 85000., 70000., 60000., 50000., 40000., 3000
                    20000., 15000., 10000., 7000., 5000., 3000., 2000., 1000., 500., 100.])
 
 
-def hybrid_coefficients(nlev, p_top_first=None):
-    """Monotone synthetic hybrid half-level coefficients (ak [Pa], bk [1]), length nlev+1."""
+def hybrid_coefficients(nlev):
+    """Monotone synthetic hybrid half-level coefficients (ak [Pa], bk [1]), length nlev+1.
+
+    Reference half-level pressures (at ps = 101325 Pa) follow p_k = 101325 (k/N)^a with a chosen
+    so that the first non-zero half level sits at 1 Pa (for N = 137: a = 2.34, 55 full levels
+    below 300 hPa - close to ECMWF's L137 distribution)."""
     n = nlev
     k = np.arange(n + 1, dtype=np.float64)
-    # reference half-level pressures at ps = 101325: geometric from ~1 Pa (L137-like top at
-    # 0.01 hPa for the first non-zero half level) to the surface
-    p1 = 1.0 if p_top_first is None else float(p_top_first)
-    p_ref = np.empty(n + 1)
+    a = np.log(101325.0) / np.log(float(n)) if n > 1 else 1.0
+    p_ref = 101325.0 * (k / n) ** a
     p_ref[0] = 0.0
-    p_ref[1:] = p1 * (101325.0 / p1) ** ((k[1:] - 1) / (n - 1))
     # b: zero above 7000 Pa, smooth monotone blend to 1 at the surface
     s = np.clip((p_ref - 7000.0) / (101325.0 - 7000.0), 0.0, 1.0)
     bk = s ** 1.6
@@ -76,30 +77,32 @@ def make_case(nlat=10, nlon=10, nlev=20, seed=0, dtype=np.float64, plev=None, ns
     fis = CON_G * orog
     ps = 101325.0 * np.exp(-orog / 8000.0) * (1 + 0.01 * np.clip(rng.standard_normal((nlat, nlon)), -3, 3))
 
-    def noise4(scale, n):
-        if not noise:
-            return np.zeros((1, n, nlat, nlon), dtype=dt)
-        return (scale * rng.standard_normal((1, n, nlat, nlon), dtype=np.float32)).astype(dt, copy=False)
-
-    pa = (akm[None, :, None, None] + ps[None, None] * bkm[None, :, None, None])
-    z = -8000.0 * np.log(pa / 101325.0)
-    T = np.maximum(288.0 - 0.0065 * z, 215.0)
-    del z
-    T = (T + noise4(1.0, nlev)).astype(dt, copy=False)
-    # humidity from RH ~ U(10,95) % through the IFS formulas (functions.py:74-125)
-    rh = rng.uniform(10.0, 95.0, (1, 1, nlat, nlon)) * np.ones((1, nlev, 1, 1))
-    T64 = T.astype(np.float64, copy=False)
+    # 3-D fields level by level (8 MB slabs stay in cache; no full-size temporaries)
+    shp4 = (1, nlev, nlat, nlon)
+    T = np.empty(shp4, dtype=dt); QV = np.empty(shp4, dtype=dt)
+    U = np.empty(shp4, dtype=dt); V = np.empty(shp4, dtype=dt)
+    rh2d = rng.uniform(10.0, 95.0, (nlat, nlon))
     T0, Ti = 273.16, 250.16
-    alpha = np.where(T64 >= T0, 1.0, np.where(T64 <= Ti, 0.0, ((T64 - Ti) / (T0 - Ti)) ** 2))
-    es = (alpha * 611.21 * np.exp(17.502 * (T64 - T0) / (T64 - 32.19)) +
-          (1 - alpha) * 611.21 * np.exp(22.587 * (T64 - T0) / (T64 + 0.7)))
-    del alpha, T64
-    e = rh / 100.0 * es
-    del es
-    QV = (0.622 * e / (pa - 0.378 * e)).astype(dt, copy=False)
-    del e, pa
-    U = noise4(10.0, nlev) if noise else np.full((1, nlev, nlat, nlon), 5.0, dtype=dt)
-    V = noise4(10.0, nlev) if noise else np.full((1, nlev, nlat, nlon), -3.0, dtype=dt)
+    f32 = np.float32
+    for l in range(nlev):
+        pa = akm[l] + ps * bkm[l]
+        t = np.maximum(288.0 + 0.0065 * 8000.0 * np.log(pa / 101325.0), 215.0)
+        if noise:
+            t = t + rng.standard_normal((nlat, nlon), dtype=f32)
+        t = t.astype(dt).astype(np.float64)           # humidity consistent with the stored T
+        # humidity from RH ~ U(10,95) % through the IFS formulas (functions.py:74-125)
+        alpha = np.where(t >= T0, 1.0, np.where(t <= Ti, 0.0, ((t - Ti) / (T0 - Ti)) ** 2))
+        es = (alpha * 611.21 * np.exp(17.502 * (t - T0) / (t - 32.19)) +
+              (1 - alpha) * 611.21 * np.exp(22.587 * (t - T0) / (t + 0.7)))
+        e = rh2d / 100.0 * es
+        T[0, l] = t
+        QV[0, l] = 0.622 * e / (pa - 0.378 * e)
+        if noise:
+            U[0, l] = 10.0 * rng.standard_normal((nlat, nlon), dtype=f32)
+            V[0, l] = 10.0 * rng.standard_normal((nlat, nlon), dtype=f32)
+        else:
+            U[0, l] = 5.0
+            V[0, l] = -3.0
 
     sic = np.clip(_smooth2d(rng, nlat, nlon) * 1.5 - 0.7, 0, 1)
     sic = np.where(land > 0.5, np.nan, sic)
@@ -120,25 +123,30 @@ def make_case(nlat=10, nlon=10, nlev=20, seed=0, dtype=np.float64, plev=None, ns
     pat = _smooth2d(rng, nlat, nlon)                            # (lat,lon) in [0,1]
     prof = np.clip(1.0 + 4.0 * np.exp(-((np.log(plev) - np.log(30000.0)) / 1.2) ** 2), 1.0, 5.0)
     prof = np.where(plev < 10000.0, 1.0 - 3.0 * (1 - plev / 10000.0), prof)   # stratospheric cooling
-    d_ta = (prof[None, :, None, None] * (0.8 + 0.2 * season[:, None, None, None]) *
-            (0.8 + 0.4 * pat[None, None]))
-    d_hur = 5.0 * (2 * _smooth2d(rng, nlat, nlon)[None, None] - 1) * \
-        np.cos(np.linspace(0, np.pi, S))[None, :, None, None] * (1 + 0.2 * season[:, None, None, None])
-    d_ua = 2.0 * (2 * _smooth2d(rng, nlat, nlon)[None, None] - 1) * np.ones((12, S, 1, 1))
-    d_va = 2.0 * (2 * _smooth2d(rng, nlat, nlon)[None, None] - 1) * np.ones((12, S, 1, 1))
+    def outer(prof_ts, pat2d):
+        """(12, S) profile x (lat, lon) pattern -> (12, S, lat, lon) in the storage dtype."""
+        o = np.empty((12, S, nlat, nlon), dtype=dt)
+        np.multiply(prof_ts.astype(dt)[:, :, None, None], pat2d.astype(dt)[None, None], out=o)
+        return o
+
+    sea = season[:, None]
+    d_ta = outer(prof[None, :] * (0.8 + 0.2 * sea), 0.8 + 0.4 * pat)
+    d_hur = outer(5.0 * np.cos(np.linspace(0, np.pi, S))[None, :] * (1 + 0.2 * sea),
+                  2 * _smooth2d(rng, nlat, nlon) - 1)
+    d_ua = outer(2.0 * np.ones((12, S)), 2 * _smooth2d(rng, nlat, nlon) - 1)
+    d_va = outer(2.0 * np.ones((12, S)), 2 * _smooth2d(rng, nlat, nlon) - 1)
     # geopotential-height delta consistent with a warmer column: grows with height
     h = np.clip(np.log(100000.0 / plev) / np.log(100000.0 / 100.0), 0, 1)
-    d_zg = (20.0 + 100.0 * h[None, :, None, None] ** 0.7) * (0.9 + 0.2 * pat[None, None]) * \
-        (1 + 0.1 * season[:, None, None, None])
+    d_zg = outer((20.0 + 100.0 * h[None, :] ** 0.7) * (1 + 0.1 * sea), 0.9 + 0.2 * pat)
     d_tas = 2.0 * (0.8 + 0.2 * season[:, None, None]) * (0.8 + 0.4 * pat[None])
     d_hurs = -2.0 * (2 * pat[None] - 1) * np.ones((12, 1, 1))
     d_ts = d_tas * 1.05
     d_tos = np.where(land[None] > 0.5, np.nan, 0.8 * d_tas)
     d_sic = -20.0 * np.clip(_smooth2d(rng, nlat, nlon), 0, 1)[None] * np.ones((12, 1, 1))
     ps_hist = ps[None] * (1 + 0.002 * (2 * _smooth2d(rng, nlat, nlon)[None] - 1)) * np.ones((12, 1, 1))
-    deltas = dict(ta=d_ta, hur=d_hur, ua=d_ua, va=d_va, zg=d_zg, tas=d_tas, hurs=d_hurs,
-                  ts=d_ts, tos=d_tos, siconc=d_sic, ps_hist=ps_hist)
-    deltas = {k: np.ascontiguousarray(v).astype(dt) for k, v in deltas.items()}
+    deltas = dict(ta=d_ta, hur=d_hur, ua=d_ua, va=d_va, zg=d_zg)
+    for k, v in dict(tas=d_tas, hurs=d_hurs, ts=d_ts, tos=d_tos, siconc=d_sic, ps_hist=ps_hist).items():
+        deltas[k] = np.ascontiguousarray(v).astype(dt)
     delta_times = np.array(['1995-%02d-15T12:00:00' % (m + 1) for m in months], dtype='datetime64[s]')
     if target_dt is None:
         target_dt = _dt.datetime(2006, 8, 2, 3)
