@@ -41,7 +41,7 @@ def parse():
     p.add_argument('--nlat', type=int, default=721)
     p.add_argument('--nlon', type=int, default=1440)
     p.add_argument('--nlev', type=int, default=137)
-    p.add_argument('--cpu-rows', type=int, default=24, help='latitude rows of the CPU-baseline sample')
+    p.add_argument('--cpu-rows', type=int, default=160, help='latitude rows of the CPU-baseline sample')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--full-column', action='store_true',
                    help='pass kernel reads every level (input-independent traffic) instead of stopping above p_ref')

@@ -458,13 +458,19 @@ extern "C" int pgw_relative_to_specific_humidity_hybrid(pgw_ctx *ctx, int dtype,
 // ------------------------------------------------------------------ integ_geopot
 static int launch_integ_geopot(pgw_ctx *ctx, int dtype, int nlev, int ntime, long long ncol, const void *pa_hl,
                                const void *zgs, const void *ta, const void *hus, double p_ref,
-                               const void *p_ref_field, void *phi_ref, int full_column) {
+                               const void *p_ref_field, void *phi_ref, int full_column, bool out_f64 = false) {
     int vec = pick_vec(dtype, ncol, {pa_hl, zgs, ta, hus, p_ref_field, phi_ref});
     Prof pr(ctx, PGW_K_INTEG_GEOPOT);
-    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, 4>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,
-                                                (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,
-                                                (const T *)p_ref_field, (T *)phi_ref, full_column, ctx->d_status));
+    if (out_f64)
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, 4, double>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                    dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,
+                                                    (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,
+                                                    (const T *)p_ref_field, (double *)phi_ref, full_column, ctx->d_status));
+    else
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, 4, T>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                    dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,
+                                                    (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,
+                                                    (const T *)p_ref_field, (T *)phi_ref, full_column, ctx->d_status));
     return PGW_OK;
 }
 
@@ -718,20 +724,18 @@ extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long 
     void *evap = nullptr, *state = nullptr, *pahl = nullptr;
     int rc;
     if ((rc = ws_get(ctx, 0, (size_t)ntime * N * ncol * es, &evap))) return rc;
-    if ((rc = ws_get(ctx, 1, (size_t)n2 * 4 * sizeof(double) + (size_t)n2 * es, &state))) return rc;
+    if ((rc = ws_get(ctx, 1, (size_t)n2 * 4 * sizeof(double), &state))) return rc;
     if ((rc = ws_get(ctx, 2, (size_t)ntime * (N + 1) * ncol * es, &pahl))) return rc;
     double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
-    void *phi_era_t = (void *)(adj_ps + n2);
     const int full_column = full_column_env();
 
     // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it)
     if ((rc = pgw_pressure_levels(ctx, dtype, ntime, ncol, PS, pahl, nullptr))) return rc;
     if ((rc = status_reset(ctx))) return rc;
-    launch_integ_geopot(ctx, dtype, N, ntime, ncol, pahl, FIS, T, QV, p_ref, nullptr, phi_era_t, 1);
+    launch_integ_geopot(ctx, dtype, N, ntime, ncol, pahl, FIS, T, QV, p_ref, nullptr, phi_era, 1, true);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = status_check(ctx))) return rc;
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((k_to_f64<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, (const T *)phi_era_t, phi_era);
         hipLaunchKernelGGL((k_scale_to_f64<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, (const T *)dzg_pref,
                            CON_G, dphi);                                   // step_03:292-293
     });

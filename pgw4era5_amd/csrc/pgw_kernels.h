@@ -156,12 +156,13 @@ __device__ __forceinline__ double geo_finish(GeoAcc &a, double p_ref, DevStatus 
     return a.phi_s - (CON_RD * a.tv_s) * (log(p_ref) - a.lnp_s);    // :174-179
 }
 
-template <typename T, int V, int U>
+// TO = type of the phi_ref output (T for the signature-faithful call, double for the loop state)
+template <typename T, int V, int U, typename TO>
 __global__ __launch_bounds__(BLOCK) void k_integ_geopot(int nlev, int ntime, long long ncol,
                                                         const T *__restrict__ pa_hl, const T *__restrict__ zgs,
                                                         const T *__restrict__ ta, const T *__restrict__ hus,
                                                         double p_ref_s, const T *__restrict__ p_ref_f,
-                                                        T *__restrict__ phi_ref, int full_column,
+                                                        TO *__restrict__ phi_ref, int full_column,
                                                         DevStatus *st) {
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
@@ -222,7 +223,7 @@ done:
     double r[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) r[v] = geo_finish(acc[v], pref[v], st, c2 + v);
-    storev<T, V>(phi_ref + c2, r);
+    storev<TO, V>(phi_ref + c2, r);
 }
 
 // =====================================================================================

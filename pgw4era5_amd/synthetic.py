@@ -94,7 +94,8 @@ def make_case(nlat=10, nlon=10, nlev=20, seed=0, dtype=np.float64, plev=None, ns
         alpha = np.where(t >= T0, 1.0, np.where(t <= Ti, 0.0, ((t - Ti) / (T0 - Ti)) ** 2))
         es = (alpha * 611.21 * np.exp(17.502 * (t - T0) / (t - 32.19)) +
               (1 - alpha) * 611.21 * np.exp(22.587 * (t - T0) / (t + 0.7)))
-        e = rh2d / 100.0 * es
+        # RH decays above 200 hPa so that the stratosphere is dry (q of a few 1e-6, e << p)
+        e = rh2d * np.clip(pa / 20000.0, 0.0, 1.0) ** 3 / 100.0 * es
         T[0, l] = t
         QV[0, l] = 0.622 * e / (pa - 0.378 * e)
         if noise:

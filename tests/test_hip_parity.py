@@ -166,6 +166,7 @@ def test_interp_logp_4d_vs_oracle(F, mode, S, N):
     v[0, 1, 2, 3] = np.nan
     if mode != 'off':
         pt[1, 0, 0, 0] = ps[1, 0, 0, 0]            # exact hit on the first source level
+        pt[1, :, 0, 0] = np.sort(pt[1, :, 0, 0])
         pt[0, :, 4, 4] = pt[0, ::-1, 4, 4].copy()  # descending target column: error in the reference
     if mode == 'off' or True:
         try:
@@ -228,7 +229,7 @@ def test_time_lerp_vs_oracle(F):
     want = O.time_lerp(b, a, tb, ta, t)
     ns = 'datetime64[ns]'
     x_hi = float((ta.astype(ns) - tb.astype(ns)).astype(np.int64)); x_new = float((t.astype(ns) - tb.astype(ns)).astype(np.int64))
-    np.testing.assert_allclose(F.time_lerp(b, a, x_hi, x_new), want, rtol=1e-14)
+    np.testing.assert_array_equal(F.time_lerp(b, a, x_hi, x_new), want)      # same operation order, no FMA contraction
 
 
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
@@ -275,7 +276,12 @@ def test_whole_file_vs_oracle(dtype):
     assert got['n_iter'] == want['n_iter']
     tol = 1e-9 if dtype == np.float64 else 1e-6
     for k in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE', 'RELHUM_pgw']:
-        np.testing.assert_allclose(got[k], want[k], rtol=tol, atol=1e-5 if (dtype == np.float32 and k in ('U', 'V', 'RELHUM_pgw')) else 1e-12,
+        rtol = tol
+        if dtype == np.float32 and k == 'QV':
+            # f32 STORAGE of the intermediate ta_pgw: e_sat(T) amplifies T's f32 rounding
+            # (1.5e-5 K at 215 K) by d ln(e_sat)/dT = 0.13 /K -> 2e-6 relative at the cold top
+            rtol = 3e-6
+        np.testing.assert_allclose(got[k], want[k], rtol=rtol, atol=1e-5 if (dtype == np.float32 and k in ('U', 'V', 'RELHUM_pgw')) else 1e-12,
                                    equal_nan=True, err_msg=k)
     # the converged state satisfies the loop's criterion when re-evaluated by the standalone oracle
     assert want['max_err'][-1] <= 0.15
