@@ -143,9 +143,11 @@ def main():
             kern[k] = dict(launches=cnt, avg_ms=round(avg_ms, 4), total_ms=round(ms, 3),
                            algo_GB=round(b / 1e9, 4), GBps=round(b / 1e9 / (avg_ms / 1e3), 1) if b else None)
         dom = max((k for k in kern if kern[k]['GBps']), key=lambda k: kern[k]['total_ms'])
+        traffic, tsrc = pmc_traffic(dom, a)
         roof = dict(bound='hbm', kernel=dom, achieved=kern[dom]['GBps'], peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), traffic=None,
-                    avg_launch_ms=kern[dom]['avg_ms'], algorithmic_GB_per_launch=kern[dom]['algo_GB'])
+                    frac=round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_unit='GB/launch',
+                    traffic_source=tsrc, avg_launch_ms=kern[dom]['avg_ms'],
+                    algorithmic_GB_per_launch=kern[dom]['algo_GB'])
         files = a.steps * world
         res = {
             'metric': 'ERA5 files/hour (0.25deg L137), step_03 hot path, inputs resident in HBM',
@@ -171,6 +173,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+PMC_KERNEL = {'integ_geopot': 'k_integ_geopot', 'adjust_ps_step': 'k_adjust_ps_step',
+              'vert_interp_delta': 'k_vert_interp_delta', 'q_to_rh': 'k_humidity_hybrid', 'rh_to_q': 'k_humidity_hybrid',
+              'finalize': 'k_finalize_ps_hus', 'pressure': 'k_pressure_levels', 'thermo_delta': 'k_thermo_delta',
+              'wind_delta': 'k_wind_delta'}
+
+
+def pmc_traffic(kernel, a):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
+    (profiles/pmc_summary_*.json, produced by profiles/summarize.py from separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command).  PMC counters cannot be read from inside the process,
+    so the number is only reported for the configuration the passes were taken on (default
+    shape, matching storage); otherwise null."""
+    import glob
+    if (a.nlat, a.nlon, a.nlev) != (721, 1440, 137):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_summary_*_%s.json' % a.storage)))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    vals = [v['hbm_bytes_per_launch'] for k, v in d.items()
+            if k.startswith(PMC_KERNEL.get(kernel, '?')) and 'hbm_bytes_per_launch' in v]
+    if not vals:
+        return None, None
+    return round(sum(vals) / len(vals) / 1e9, 4), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(case, a, np):

@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output directories (under gpurun_out/) into the small tracked summaries
+in profiles/.
+
+    python profiles/summarize.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+
+stats_dir: output of  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py ...
+pmc dirs : output of  rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d <dir> -- python3 bench.py ...
+                      rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir> -- python3 bench.py ...
+(separate passes, as MI355X_MICROARCH.md "rocprofv3 PMC slots" requires).
+
+HBM traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 B: both counters are in KiB and on
+gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read
+(MI355X_MICROARCH.md, section HBM); WRITE_SIZE is exact for streaming stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    name = name.split('(')[0]
+    return name.replace('pgw::', '')
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = {}
+    f = glob.glob(os.path.join(stats_dir, '**', '*_kernel_stats.csv'), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(here, 'kernel_stats_%s.csv' % tag), 'w') as o:
+        o.write('kernel,calls,avg_us,min_us,max_us,total_ms,percent\n')
+        for r in rows:
+            o.write('%s,%s,%.1f,%.1f,%.1f,%.3f,%s\n' % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3,
+                                                      float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3,
+                                                      float(r['TotalDurationNs']) / 1e6, r['Percentage']))
+            out.setdefault(short(r['Name']), {})['avg_us'] = float(r['AverageNs']) / 1e3
+    if len(sys.argv) >= 5:
+        for kind, d in (('FETCH_SIZE', sys.argv[3]), ('WRITE_SIZE', sys.argv[4])):
+            f = glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)[0]
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r['Counter_Name'] == kind:
+                    agg[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+            for k, v in agg.items():
+                out.setdefault(k, {})[kind + '_KiB'] = sum(v) / len(v)
+        for k, v in out.items():
+            if 'FETCH_SIZE_KiB' in v and 'WRITE_SIZE_KiB' in v:
+                v['hbm_bytes_per_launch'] = (2 * v['FETCH_SIZE_KiB'] + v['WRITE_SIZE_KiB']) * 1024
+    with open(os.path.join(here, 'pmc_summary_%s.json' % tag), 'w') as o:
+        json.dump(out, o, indent=1, sort_keys=True)
+    for k, v in sorted(out.items()):
+        print(k, v)
+
+
+if __name__ == '__main__':
+    main()
