@@ -423,3 +423,105 @@ def regrid_field(field, src_lat, src_lon, targ_lat, targ_lon):
         c['lon_Dx'].ctypes.data_as(_dp), c['lon_oob'].ctypes.data_as(_ip),
         tb['south_row'], tb['north_row'], out.ptr))
     return _out(ctx, out, field)
+
+
+# ------------------------------------------------------------------------------- delta files
+_DATASET_CACHE = {}
+
+
+def _open_cached(path):
+    """Delta files are read once per process (the reference re-opens them per call,
+    functions.py:203-204, i.e. ~14x per ERA5 file plus once per iteration)."""
+    from . import ncio
+    key = os.path.abspath(path)
+    st = os.stat(key)
+    hit = _DATASET_CACHE.get(key)
+    if hit is None or hit[0] != (st.st_mtime_ns, st.st_size):
+        _DATASET_CACHE[key] = ((st.st_mtime_ns, st.st_size), ncio.open_dataset(key))
+    return _DATASET_CACHE[key][1]
+
+
+def load_delta(delta_input_dir, var_name, era5_date_time, target_date_time=None,
+               name_base=file_name_bases['SCEN-HIST']):
+    """Load a climate delta and, if target_date_time is given, interpolate it linearly to that
+    time of the year (periodic, Feb-29 dropped).  reference functions.py:195-303.
+    Returns a labelled array (time, [plev,] lat, lon); time has length 1 when interpolated and is
+    stamped with `era5_date_time` (:296)."""
+    from . import ncio
+    from .step_03_apply_to_era import delta_time_bracket
+    ds = _open_cached(os.path.join(delta_input_dir, name_base.format(var_name)))
+    fld = ds[var_name]
+    times = np.asarray(ds[TIME_GCM].values)
+    if fld.dims[0] != TIME_GCM:
+        raise ValueError('first dimension of %s must be %s' % (var_name, TIME_GCM))
+    ib, ia, x_hi, x_new, keep = delta_time_bracket(times, times[0] if target_date_time is None else target_date_time)
+    if target_date_time is None:                                    # :298-301
+        return ncio.Field(fld.values[keep], fld.dims, dict(fld.coords, **{TIME_GCM: times[keep]}), fld.attrs, var_name)
+    vb = fld.values[keep[ib]]
+    if x_hi == 0.0:                                                 # :282-283
+        val = np.array(vb, copy=True)
+    else:                                                           # :288-292 on the GPU
+        val = time_lerp(vb, fld.values[keep[ia]], x_hi, x_new)
+    t = np.asarray(getattr(era5_date_time, 'values', era5_date_time)).reshape(-1)[:1]
+    coords = dict(fld.coords)
+    coords[TIME_GCM] = t
+    return ncio.Field(val[None], fld.dims, coords, fld.attrs, var_name)
+
+
+def load_delta_interp(delta_input_dir, var_name, target_P, era5_date_time, target_date_time,
+                      ignore_top_pressure_error=False):
+    """load_delta + (for ta, hur) the surface delta and HIST surface pressure + vertical
+    interpolation onto the model levels.  reference functions.py:306-340."""
+    delta = load_delta(delta_input_dir, var_name, era5_date_time, target_date_time)
+    if var_name in ['ta', 'hur']:
+        delta_sfc = load_delta(delta_input_dir, var_name + 's', era5_date_time, target_date_time)
+        ps_hist = load_delta(delta_input_dir, 'ps', era5_date_time, target_date_time,
+                             name_base=file_name_bases['HIST'])
+    else:
+        delta_sfc = ps_hist = None
+    return vert_interp_delta(delta, target_P, delta_sfc, ps_hist, ignore_top_pressure_error)
+
+
+# ------------------------------------------------------------------------------- step_02
+def regrid_lat_lon(ds_gcm, ds_era5, var_name, method='bilinear', i_use_xesmf=0):
+    """Bilinear regridding of every lat/lon variable of `ds_gcm` onto the ERA5 grid of
+    `ds_era5` (xarray branch of reference functions.py:748-898; the xESMF branch is not part of
+    this build - SURVEY.md section 8c).  Returns a new Dataset on the target grid."""
+    from . import ncio
+    if i_use_xesmf:
+        raise NotImplementedError('the xESMF regridding branch (functions.py:797-810) is out of scope; '
+                                  'set i_use_xesmf_regridding = 0')
+    targ_lon = np.asarray(ds_era5[LON_ERA].values, dtype=np.float64)
+    targ_lat = np.asarray(ds_era5[LAT_ERA].values, dtype=np.float64)
+    src_lon = np.asarray(ds_gcm[LON_GCM].values, dtype=np.float64)
+    src_lat = np.asarray(ds_gcm[LAT_GCM].values, dtype=np.float64)
+    out = ncio.Dataset(attrs=ds_gcm.attrs)
+    for name, f in ds_gcm.variables.items():
+        if name in (LAT_GCM, LON_GCM):
+            continue
+        if LAT_GCM in f.dims and LON_GCM in f.dims:
+            lead = [d for d in f.dims if d not in (LAT_GCM, LON_GCM)]
+            g = f.transpose(*(lead + [LAT_GCM, LON_GCM]))
+            vals = g.values if g.values.dtype in (np.float32, np.float64) else g.values.astype(np.float64)
+            res = regrid_field(vals, src_lat, src_lon, targ_lat, targ_lon)
+            coords = {d: f.coords[d] for d in lead if d in f.coords}
+            coords[LAT_GCM] = targ_lat
+            coords[LON_GCM] = targ_lon
+            out[name] = ncio.Field(res, tuple(lead) + (LAT_GCM, LON_GCM), coords, f.attrs, name)
+        elif LAT_GCM not in f.dims and LON_GCM not in f.dims:
+            out[name] = f
+    out[LAT_GCM] = ncio.Field(targ_lat, (LAT_GCM,), {LAT_GCM: targ_lat}, ds_gcm[LAT_GCM].attrs, LAT_GCM)
+    out[LON_GCM] = ncio.Field(targ_lon, (LON_GCM,), {LON_GCM: targ_lon}, ds_gcm[LON_GCM].attrs, LON_GCM)
+    return out
+
+
+def interp_wrapper(origin_grid, target_grid, var_name, i_use_xesmf=0,
+                   nan_interp_kernel_radius=300000, nan_interp_sharpness=3):
+    """Per-variable choice of the regridding scheme (reference functions.py:1062-1141).
+    Atmospheric variables: bilinear on the GPU.  `tos` / `siconc` use the reference's
+    pyvista/VTK point-cloud interpolation (functions.py:900-1060), which is outside this build
+    (SURVEY.md section 2 / 8 f rank 4)."""
+    if var_name in ['tos', 'siconc']:
+        raise NotImplementedError('NaN-ignoring ocean-grid interpolation (functions.py:900-1060, pyvista/VTK) '
+                                  'is out of scope of the MI355X hot path; run the reference for %s' % var_name)
+    return regrid_lat_lon(origin_grid, target_grid, var_name, method='bilinear', i_use_xesmf=i_use_xesmf)

@@ -1,0 +1,128 @@
+"""
+File-level fan-out: one process per GPU (replaces the reference's `parallel.py`).
+
+The reference distributes ERA5 files over a `multiprocessing.Pool`
+(reference parallel.py:18-32, 53-68: `IterMP(njobs, run_async).run(func, fargs, step_args)`,
+results in `.output`).  Files are independent units (step_03_apply_to_era.py:611-638), so the
+MI355X equivalent is a rank-per-GPU launcher: task `i` goes to rank `i mod W`, every rank binds
+to GPU `LOCAL_RANK`, there is no data-path collective, and the only communication is one
+barrier plus an object gather of the (small) return values:
+
+  * under `torchrun` / `python -m torch.distributed.run` (WORLD_SIZE > 1 in the environment)
+    each rank runs its shard; `torch.distributed` with backend "nccl" (= RCCL) on GPUs, "gloo"
+    on CPU-only hosts (tests);
+  * started as a plain process with njobs > 1, `run` spawns njobs workers itself
+    (`multiprocessing` spawn context, LOCAL_RANK = worker index) - same interface as the
+    reference's `-p N`;
+  * njobs == 1: serial loop in this process, like the reference.
+"""
+import multiprocessing as mp
+import os
+import sys
+
+
+def shard_indices(ntasks, rank, world):
+    """Round-robin deal of task indices to ranks."""
+    return list(range(rank, ntasks, world))
+
+
+def _merge(fargs, step_args):
+    tasks = []
+    for s in step_args:
+        kw = dict(fargs)
+        kw.update(s)
+        tasks.append(kw)
+    return tasks
+
+
+def _worker(rank, world, func, tasks, queue):
+    os.environ['LOCAL_RANK'] = str(rank)
+    os.environ['PGW_RANK'] = str(rank)
+    try:
+        out = [(i, func(**tasks[i])) for i in shard_indices(len(tasks), rank, world)]
+        queue.put((rank, out, None))
+    except BaseException as e:   # noqa: BLE001 - reported to the parent, which re-raises
+        queue.put((rank, [], '%s: %s' % (type(e).__name__, e)))
+
+
+def _dist_env():
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    return rank, world
+
+
+class IterMP:
+    """`IterMP(njobs=None, run_async=False).run(func, fargs={}, step_args=None)`; results of
+    all tasks, in task order, in `.output` (reference parallel.py:36-68)."""
+
+    def __init__(self, njobs=None, run_async=False, backend=None):
+        self.run_async = run_async
+        if njobs is None:
+            njobs = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1
+        self.njobs = int(njobs)
+        self.backend = backend
+        self.output = None
+        print('IterMP: njobs = ' + str(self.njobs))
+
+    def run(self, func, fargs={}, step_args=None):
+        tasks = _merge(fargs, step_args or [])
+        rank, world = _dist_env()
+        if world > 1:
+            self.output = self._run_distributed(func, tasks, rank, world)
+        elif self.njobs > 1 and len(tasks) > 1:
+            self.output = self._run_spawn(func, tasks, min(self.njobs, len(tasks)))
+        else:
+            self.output = [func(**kw) for kw in tasks]
+        return self.output
+
+    # one process per GPU, launched by torchrun
+    def _run_distributed(self, func, tasks, rank, world):
+        import torch                      # before any HIP call of libpgw_hip.so (see _lib.py)
+        import torch.distributed as dist
+        created = False
+        if not dist.is_initialized():
+            backend = self.backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+            if backend == 'nccl':
+                torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+            dist.init_process_group(backend)
+            created = True
+        err = None
+        mine = []
+        try:
+            mine = [(i, func(**tasks[i])) for i in shard_indices(len(tasks), rank, world)]
+        except Exception as e:            # noqa: BLE001 - every rank must reach the gather
+            err = '%s: %s' % (type(e).__name__, e)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (mine, err))
+        dist.barrier()
+        if created:
+            dist.destroy_process_group()
+        errs = [e for _, e in gathered if e]
+        if errs:
+            raise RuntimeError('worker failed: ' + '; '.join(errs))
+        out = [None] * len(tasks)
+        for part, _ in gathered:
+            for i, r in part:
+                out[i] = r
+        return out
+
+    # self-spawned workers (plain `python step_03... -p N`)
+    def _run_spawn(self, func, tasks, world):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(r, world, func, tasks, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = [None] * len(tasks)
+        errs = []
+        for _ in procs:
+            rank, part, err = q.get()
+            if err:
+                errs.append('rank %d: %s' % (rank, err))
+            for i, r in part:
+                out[i] = r
+        for p in procs:
+            p.join()
+        if errs:
+            raise RuntimeError('worker failed: ' + '; '.join(errs))
+        return out

@@ -235,3 +235,136 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     res['RELHUM_pgw'] = out['_hur_pgw'].numpy()
     res.update(info)
     return res
+
+
+# ----------------------------------------------------------------------------------------
+# file-level driver: pgw_for_era5 and the command line
+# ----------------------------------------------------------------------------------------
+_DELTASETS = {}
+
+
+def load_delta_set(ctx, delta_input_dir, dtype):
+    """All delta files of a directory -> DeltaSet on the device, cached per process (every
+    ERA5 file of a run uses the same deltas)."""
+    from . import ncio
+    key = (os.path.abspath(delta_input_dir), np.dtype(dtype).str, ctx.device)
+    if key in _DELTASETS:
+        return _DELTASETS[key]
+    arrays, times, plev = {}, None, None
+    for var in DeltaSet.VARS_3D + ('tas', 'hurs', 'ts', 'tos', 'siconc'):
+        ds = ncio.open_dataset(os.path.join(delta_input_dir, S.file_name_bases['SCEN-HIST'].format(var)))
+        arrays[var] = ds[var].values
+        t = np.asarray(ds[S.TIME_GCM].values)
+        if times is None:
+            times = t
+        elif len(t) != len(times) or np.any(t != times):
+            raise ValueError('time axis of %s differs from the other delta files' % var)
+        if var in DeltaSet.VARS_3D:
+            p = np.asarray(ds[S.PLEV_GCM].values, dtype=np.float64)
+            if plev is None:
+                plev = p
+            elif len(p) != len(plev) or np.any(p != plev):
+                raise ValueError('plev axis of %s differs from the other delta files' % var)
+    ds = ncio.open_dataset(os.path.join(delta_input_dir, S.file_name_bases['HIST'].format('ps')))
+    arrays['ps_hist'] = ds['ps'].values
+    dset = DeltaSet(ctx, arrays, times, plev, dtype)
+    _DELTASETS[key] = dset
+    return dset
+
+
+def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt,
+                 ignore_top_pressure_error, debug_mode=None):
+    """Apply the PGW deltas to one ERA5 file (reference step_03_apply_to_era.py:44-381)."""
+    from . import ncio
+    if debug_mode is not None:
+        raise NotImplementedError('debug_mode (step_03_apply_to_era.py:350-361, 387-414) is a validation aid of '
+                                  'the reference and not part of the MI355X hot path')
+    if S.i_reinterp or S.p_ref_inp is None:
+        raise NotImplementedError('i_reinterp = 1 and p_ref_inp = None are not built yet (SURVEY.md section 8 f)')
+    if S.i_debug >= 0:
+        print('Start working on input file {}'.format(inp_era_file_path))
+    ctx = default_context()
+    era_file = ncio.open_dataset(inp_era_file_path, decode_times=False)      # step_03:60
+    vm = S.var_name_map
+    dtype = np.dtype('float64') if era_file[vm['ta']].dtype == np.float64 else np.dtype('float32')
+    dims4 = (S.TIME_ERA, S.LEV_ERA, S.LAT_ERA, S.LON_ERA)
+    dims3 = (S.TIME_ERA, S.LAT_ERA, S.LON_ERA)
+
+    def get(name, dims):
+        return np.ascontiguousarray(era_file[name].transpose(*dims).values, dtype=dtype)
+
+    era = dict(PS=get(vm['ps'], dims3), FIS=get(vm['zgs'], dims3), T=get(vm['ta'], dims4), QV=get(vm['hus'], dims4),
+               U=get(vm['ua'], dims4), V=get(vm['va'], dims4), T_SKIN=get(vm['ts'], dims3),
+               T_SO=get(vm['st'], (S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA)),
+               FR_LAND=get(vm['sftlf'], dims3), FR_SEA_ICE=get(vm['sic'], dims3))
+    coeffs = dict(ak=np.asarray(era_file['ak'].values, dtype=np.float64), bk=np.asarray(era_file['bk'].values, dtype=np.float64),
+                  soil1=np.asarray(era_file[S.SOIL_HLEV_ERA].values, dtype=np.float64))
+    if 'akm' in era_file:                                                    # step_03:68-70
+        coeffs['akm'] = np.asarray(era_file['akm'].values, dtype=np.float64)
+        coeffs['bkm'] = np.asarray(era_file['bkm'].values, dtype=np.float64)
+    deltas = load_delta_set(ctx, delta_input_dir, dtype)
+    e = _upload_era(ctx, era, dtype)
+    out, info = process_file_device(ctx, e, coeffs, deltas, era_step_dt, ignore_top_pressure_error)
+    if S.i_debug >= 2:
+        for it, err in enumerate(info['max_err']):
+            print('### iteration {:03d}, phi max error: {}'.format(it + 1, err))
+    # write back (step_03:369-378): PS, T, QV, U, V (+ T_SKIN, T_SO, FR_SEA_ICE updated in place :105-144)
+    names = dict(PS=(vm['ps'], dims3), T=(vm['ta'], dims4), QV=(vm['hus'], dims4), U=(vm['ua'], dims4), V=(vm['va'], dims4),
+                 T_SKIN=(vm['ts'], dims3), T_SO=(vm['st'], (S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA)),
+                 FR_SEA_ICE=(vm['sic'], dims3))
+    for key, (name, dims) in names.items():
+        old = era_file[name]
+        era_file[name] = ncio.Field(out[key].numpy(), dims, {d: old.coords[d] for d in dims if d in old.coords}, old.attrs)
+    ncio.to_netcdf(era_file, out_era_file_path)
+    if S.i_debug >= 1:
+        print('Done. Saved to file {}.'.format(out_era_file_path))
+    return info['n_iter']
+
+
+def _cli(argv=None):
+    import argparse
+    from pathlib import Path
+    from .parallel import IterMP
+    p = argparse.ArgumentParser(description='Perturb ERA5 files with PGW climate deltas on MI355X GPUs '
+                                            '(flags of the reference step_03_apply_to_era.py:505-568; settings in settings.py).')
+    p.add_argument('-i', '--input_dir', type=str, default=None, help='directory with the ERA5 input files')
+    p.add_argument('-o', '--output_dir', type=str, default=None, help='directory for the processed ERA5 files')
+    p.add_argument('-f', '--first_era_step', type=str, default='2006080200', help='first time step, YYYYMMDDHH')
+    p.add_argument('-l', '--last_era_step', type=str, default='2006080300', help='last time step (inclusive), YYYYMMDDHH')
+    p.add_argument('-H', '--hour_inc_step', type=int, default=3, help='hours between time steps')
+    p.add_argument('-d', '--delta_input_dir', type=str, default=None,
+                   help='directory with the regridded climate deltas (output of step_02) and ps_historical.nc')
+    p.add_argument('-p', '--n_par', type=int, default=1, help='number of worker ranks = GPUs; files are dealt round-robin')
+    p.add_argument('-t', '--ignore_top_pressure_error', action='store_true',
+                   help='do not fail if ERA5 reaches higher than the climate deltas')
+    p.add_argument('-D', '--debug_mode', type=str, default=None, help='interpolate_time | interpolate_full (not built)')
+    args = p.parse_args(argv)
+    if args.input_dir is None:
+        raise ValueError('Input directory (-i) is required.')
+    if args.output_dir is None:
+        raise ValueError('Output directory (-o) is required.')
+    if args.delta_input_dir is None:
+        raise ValueError('Delta input directory (-d) is required.')
+    if args.debug_mode is not None and args.debug_mode not in ['interpolate_time', 'interpolate_full']:
+        raise ValueError('Invalid input for argument --debug_mode! Valid arguments are: "interpolate_time" or "interpolate_full"')
+    first = _dt.datetime.strptime(args.first_era_step, '%Y%m%d%H')
+    last = _dt.datetime.strptime(args.last_era_step, '%Y%m%d%H')
+    inc = _dt.timedelta(hours=args.hour_inc_step)
+    steps = []
+    t = first
+    while t < last + inc:                                   # np.arange(first, last + inc, inc), step_03:594-596
+        steps.append(t)
+        t += inc
+    Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+    fargs = dict(delta_input_dir=args.delta_input_dir, ignore_top_pressure_error=args.ignore_top_pressure_error,
+                 debug_mode=args.debug_mode)
+    step_args = [dict(inp_era_file_path=os.path.join(args.input_dir, S.era5_file_name_base.format(s)),
+                      out_era_file_path=os.path.join(args.output_dir, S.era5_file_name_base.format(s)),
+                      era_step_dt=s) for s in steps]
+    imp = IterMP(njobs=args.n_par, run_async=True)
+    imp.run(pgw_for_era5, fargs, step_args)
+    return imp.output
+
+
+if __name__ == '__main__':
+    _cli()

@@ -171,3 +171,54 @@ def make_gcm_grid_case(nlat_src=48, nlon_src=96, nlat=37, nlon=72, nplev=5, ntim
     targ_lon = np.arange(nlon) * (360.0 / nlon)
     f = rng.standard_normal((ntime, nplev, nlat_src, nlon_src)).astype(dtype)
     return dict(field=f, src_lat=src_lat, src_lon=src_lon, targ_lat=targ_lat, targ_lon=targ_lon)
+
+
+def write_case_files(case, era_dir, delta_dir, era_name=None):
+    """Write a make_case() result as the NetCDF-3 files the step_03 driver reads: one ERA5 file
+    (reference file schema) and the delta directory ({var}_delta.nc,
+    ps_historical.nc).  Returns the ERA5 file path."""
+    import os
+    from . import ncio, settings as S
+    os.makedirs(era_dir, exist_ok=True)
+    os.makedirs(delta_dir, exist_ok=True)
+    era, lat, lon = case['era'], case['lat'], case['lon']
+    nlev = era['T'].shape[1]
+    F = ncio.Field
+    ds = ncio.Dataset(attrs=dict(title='synthetic ERA5 file (pgw4era5_amd.synthetic)'))
+    tsec = (np.datetime64(case['target_dt']).astype('datetime64[s]') - np.datetime64('1970-01-01T00:00:00')).astype(np.float64)
+    cv = dict(time=np.array([tsec]), level=np.arange(1, nlev + 1, dtype=np.float64),
+              level1=np.arange(1, nlev + 2, dtype=np.float64), soil1=np.asarray(era['soil1'], dtype=np.float64),
+              lat=np.asarray(lat, dtype=np.float64), lon=np.asarray(lon, dtype=np.float64))
+    for k, v in cv.items():
+        attrs = dict(units='seconds since 1970-01-01 00:00:00') if k == 'time' else {}
+        ds[k] = F(v, (k,), {k: v}, attrs)
+    ds['ak'] = F(era['ak'], ('level1',), {'level1': cv['level1']})
+    ds['bk'] = F(era['bk'], ('level1',), {'level1': cv['level1']})
+    d4 = ('time', 'level', 'lat', 'lon')
+    d3 = ('time', 'lat', 'lon')
+    for name in ('T', 'QV', 'U', 'V'):
+        ds[name] = F(era[name], d4, {d: cv[d] for d in d4})
+    for name in ('PS', 'FIS', 'T_SKIN', 'FR_LAND', 'FR_SEA_ICE'):
+        ds[name] = F(era[name], d3, {d: cv[d] for d in d3})
+    ds['T_SO'] = F(era['T_SO'], ('time', 'soil1', 'lat', 'lon'), {d: cv[d] for d in ('time', 'soil1', 'lat', 'lon')})
+    name = era_name or S.era5_file_name_base.format(case['target_dt'])
+    path = os.path.join(era_dir, name)
+    ncio.to_netcdf(ds, path)
+    # deltas
+    times = case['delta_times']
+    tdays = (times - np.datetime64('1850-01-01T00:00:00')).astype('timedelta64[s]').astype(np.float64) / 86400.0
+    for var, arr in case['deltas'].items():
+        dd = ncio.Dataset()
+        dd['time'] = F(tdays, ('time',), attrs=dict(units='days since 1850-01-01 00:00:00', calendar='proleptic_gregorian'))
+        dd['lat'] = F(cv['lat'], ('lat',))
+        dd['lon'] = F(cv['lon'], ('lon',))
+        if arr.ndim == 4:
+            dd['plev'] = F(np.asarray(case['plev'], dtype=np.float64), ('plev',), attrs=dict(units='Pa'))
+            dims = ('time', 'plev', 'lat', 'lon')
+        else:
+            dims = ('time', 'lat', 'lon')
+        vname, fname = (('ps', S.file_name_bases['HIST'].format('ps')) if var == 'ps_hist'
+                        else (var, S.file_name_bases['SCEN-HIST'].format(var)))
+        dd[vname] = F(arr, dims)
+        ncio.to_netcdf(dd, os.path.join(delta_dir, fname))
+    return path

@@ -1,0 +1,114 @@
+"""GPU tests of the file-level drivers (step_03 / step_02 command lines, load_delta*) on
+synthetic NetCDF-3 files, against the oracle evaluated on the same arrays."""
+import datetime as dt
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pgw_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def files(tmp_path_factory):
+    from pgw4era5_amd import synthetic
+    root = tmp_path_factory.mktemp('pgw')
+    cases = []
+    for h in (0, 3):
+        c = synthetic.make_case(6, 8, 12, seed=11, dtype=np.float32, target_dt=dt.datetime(2006, 8, 2, h))
+        synthetic.write_case_files(c, str(root / 'era'), str(root / 'deltas'))
+        cases.append(c)
+    return root, cases
+
+
+def _oracle(c):
+    era64 = {k: (np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
+             for k, v in c['era'].items()}
+    d64 = {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()}
+    return O.pgw_for_era5_arrays(era64, d64, c['delta_times'], c['plev'], c['target_dt'], True)
+
+
+def test_step03_cli_end_to_end(files):
+    from pgw4era5_amd import step_03_apply_to_era as s3, ncio
+    root, cases = files
+    out_dir = str(root / 'out')
+    n_iters = s3._cli(['-i', str(root / 'era'), '-o', out_dir, '-d', str(root / 'deltas'),
+                       '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '1', '-t'])
+    assert len(n_iters) == 2
+    for c, n in zip(cases, n_iters):
+        want = _oracle(c)
+        assert n == want['n_iter']
+        ds = ncio.open_dataset(os.path.join(out_dir, 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])), decode_times=False)
+        assert 'RELHUM' not in ds
+        for name in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+            np.testing.assert_allclose(ds[name].values, want[name], rtol=3e-6 if name == 'QV' else 1e-6, atol=1e-5 if name in 'UV' else 1e-12,
+                                       equal_nan=True, err_msg=name)
+        np.testing.assert_array_equal(ds['FIS'].values, c['era']['FIS'])      # untouched variables pass through
+        np.testing.assert_array_equal(ds['ak'].values, c['era']['ak'])
+
+
+def test_step03_top_pressure_error_without_t(files):
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    root, cases = files
+    with pytest.raises(ValueError) as e:
+        s3._cli(['-i', str(root / 'era'), '-o', str(root / 'out2'), '-d', str(root / 'deltas'),
+                 '-f', '2006080200', '-l', '2006080200', '-H', '3'])
+    assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
+
+
+def test_load_delta_and_interp(files):
+    from pgw4era5_amd import functions as F
+    root, cases = files
+    c = cases[1]
+    ddir = str(root / 'deltas')
+    era_time = np.array([0.0])
+    got = F.load_delta(ddir, 'ta', era_time, c['target_dt'])
+    want = O.load_delta_values(np.asarray(c['deltas']['ta'], dtype=np.float64), c['delta_times'], c['target_dt'])
+    assert got.dims == ('time', 'plev', 'lat', 'lon') and got.shape == want.shape
+    np.testing.assert_allclose(got.values, want, rtol=1e-6)
+    full = F.load_delta(ddir, 'ts', era_time, None)
+    assert full.shape[0] == 12
+    exact = F.load_delta(ddir, 'tas', era_time, dt.datetime(2006, 3, 15, 12))
+    np.testing.assert_array_equal(exact.values[0], c['deltas']['tas'][2])
+    ps_h = F.load_delta(ddir, 'ps', era_time, c['target_dt'], name_base='{}_historical.nc')
+    assert ps_h.shape == (1, 6, 8)
+    # load_delta_interp == oracle vert_interp_delta of the time-interpolated pieces
+    era = c['era']
+    _, pa = O.hybrid_pressure(era['ak'], era['bk'], np.asarray(era['PS'], dtype=np.float64))
+    gi = F.load_delta_interp(ddir, 'hur', pa, era_time, c['target_dt'], ignore_top_pressure_error=True)
+    ld = lambda k: O.load_delta_values(np.asarray(c['deltas'][k], dtype=np.float64), c['delta_times'], c['target_dt'])
+    wi = O.vert_interp_delta(ld('hur'), c['plev'], pa, ld('hurs'), ld('ps_hist'), ignore_top_pressure_error=True)
+    np.testing.assert_allclose(gi, wi, rtol=1e-6, atol=1e-6)
+
+
+def test_step02_cli_regridding(tmp_path):
+    from pgw4era5_amd import synthetic, ncio, step_02_preproc_deltas as s2
+    g = synthetic.make_gcm_grid_case(nlat_src=24, nlon_src=48, nlat=19, nlon=36, nplev=4, ntime=12, seed=5)
+    inp, out = tmp_path / 'gcm', tmp_path / 'regridded'
+    os.makedirs(inp)
+    F = ncio.Field
+    times = np.array(['1995-%02d-15T12:00:00' % m for m in range(1, 13)], dtype='datetime64[s]')
+    plev = np.array([100000., 85000., 50000., 30000.])
+    for base in ('ta_delta.nc', 'ta_historical.nc'):
+        ds = ncio.Dataset()
+        ds['time'] = F(times, ('time',)); ds['plev'] = F(plev, ('plev',))
+        ds['lat'] = F(g['src_lat'], ('lat',)); ds['lon'] = F(g['src_lon'], ('lon',))
+        ds['ta'] = F(g['field'], ('time', 'plev', 'lat', 'lon'), attrs=dict(units='K'))
+        ncio.to_netcdf(ds, str(inp / base))
+    era = ncio.Dataset()
+    era['lat'] = F(g['targ_lat'], ('lat',)); era['lon'] = F(g['targ_lon'], ('lon',))
+    era['FR_LAND'] = F(np.zeros((1, 19, 36)), ('time', 'lat', 'lon'))
+    era['time'] = F(np.array([0.0]), ('time',))
+    ncio.to_netcdf(era, str(tmp_path / 'era.nc'))
+    done = s2.main(['regridding', '-i', str(inp), '-o', str(out), '-e', str(tmp_path / 'era.nc'), '-v', 'ta'])
+    assert len(done) == 2
+    res = ncio.open_dataset(str(out / 'ta_delta.nc'))
+    want = O.regrid_lat_lon(g['field'], g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon'])
+    np.testing.assert_allclose(res['ta'].values, want, rtol=1e-12, atol=1e-14)
+    np.testing.assert_array_equal(res['lat'].values, g['targ_lat'])
+    np.testing.assert_array_equal(res['plev'].values, plev)
+    assert res['ta'].attrs['units'] == 'K'
+    with pytest.raises(NotImplementedError):
+        s2.main(['regridding', '-i', str(inp), '-o', str(out), '-e', str(tmp_path / 'era.nc'), '-v', 'tos'])

@@ -1,0 +1,190 @@
+"""CPU tests of the host-side logic around the hot path: NetCDF-3 labelled I/O, CF time
+decoding, delta time bracketing (reference functions.py:224-283), regridding tables
+(functions.py:774-893) and the rank-per-GPU launcher (replacement of parallel.py) incl. a
+world_size-2 gloo run."""
+import datetime as dt
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pgw_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ncio_roundtrip_and_labels(tmp_path):
+    from pgw4era5_amd import ncio
+    ds = ncio.Dataset(attrs=dict(title='t'))
+    lat = np.linspace(-10, 10, 5); lon = np.arange(4) * 2.0
+    ds['lat'] = ncio.Field(lat, ('lat',)); ds['lon'] = ncio.Field(lon, ('lon',))
+    t = np.array(['1995-01-15T12:00:00', '1995-02-14T00:00:00'], dtype='datetime64[s]')
+    ds['time'] = ncio.Field(t, ('time',))
+    v = np.random.default_rng(0).normal(size=(2, 5, 4)).astype(np.float32); v[0, 1, 2] = np.nan
+    ds['tas'] = ncio.Field(v, ('time', 'lat', 'lon'), attrs=dict(units='K'))
+    p = str(tmp_path / 'a.nc')
+    ncio.to_netcdf(ds, p)
+    back = ncio.open_dataset(p)
+    np.testing.assert_array_equal(back['tas'].values, v)
+    assert back['tas'].dims == ('time', 'lat', 'lon') and back['tas'].attrs['units'] == 'K'
+    np.testing.assert_array_equal(back['time'].values, t)
+    np.testing.assert_array_equal(back['tas'].coords['lat'], lat)
+    raw = ncio.open_dataset(p, decode_times=False)
+    assert raw['time'].values.dtype.kind == 'f'
+    tr = back['tas'].transpose('lon', 'time', 'lat')
+    assert tr.shape == (4, 2, 5)
+    with pytest.raises(IOError):
+        open(tmp_path / 'b.nc', 'wb').write(b'\x89HDF\r\n\x1a\n' + b'0' * 100)
+        ncio.open_dataset(str(tmp_path / 'b.nc'))
+
+
+def test_decode_cf_time_calendars():
+    from pgw4era5_amd.ncio import decode_cf_time
+    got = decode_cf_time([0, 31, 59.5], 'days since 1850-01-01 00:00:00', 'proleptic_gregorian')
+    assert str(got[1]) == '1850-02-01T00:00:00' and str(got[2]) == '1850-03-01T12:00:00'
+    # noleap: day 59 of year is always March 1st, also in leap years
+    got = decode_cf_time([365 * 146 + 59], 'days since 1850-01-01', 'noleap')
+    assert str(got[0]) == '1996-03-01T00:00:00'
+    got = decode_cf_time([15.5], 'days since 1995-01-01 00:00:00', '360_day')
+    assert str(got[0]) == '1995-01-16T12:00:00'
+    got = decode_cf_time([3600 * 5], 'seconds since 1970-01-01 00:00:00')
+    assert str(got[0]) == '1970-01-01T05:00:00'
+    with pytest.raises(ValueError):
+        decode_cf_time([0], 'fortnights since 1850-01-01')
+
+
+def test_time_bracket_matches_oracle():
+    from pgw4era5_amd.step_03_apply_to_era import delta_time_bracket
+    times = np.array(['1995-%02d-15T12:00:00' % m for m in range(1, 13)], dtype='datetime64[s]')
+    for tgt in ['2006-08-02T03:00:00', '2006-01-03T00:00:00', '2006-12-31T21:00:00', '2006-03-15T12:00:00',
+                '2008-02-29T06:00:00']:
+        ib, ia, x_hi, x_new, keep = delta_time_bracket(times, np.datetime64(tgt))
+        ob, oa, tb, ta, okeep = O.delta_time_bracket(times, np.datetime64(tgt))
+        assert (ib, ia) == (ob, oa) and list(keep) == list(okeep)
+        if ib != ia:
+            ns = 'datetime64[ns]'
+            assert x_hi == float((ta.astype(ns) - tb.astype(ns)).astype(np.int64))
+            assert x_new == float((np.datetime64(tgt).astype(ns) - tb.astype(ns)).astype(np.int64))
+            assert 0 <= x_new <= x_hi
+        else:
+            assert x_hi == 0.0
+    # python datetime target (what the CLI passes)
+    ib, ia, *_ = delta_time_bracket(times, dt.datetime(2006, 8, 2, 3))
+    assert (ib, ia) == (6, 7)
+    daily = np.arange(np.datetime64('1996-01-01'), np.datetime64('1997-01-01')).astype('datetime64[s]')
+    ib, ia, x_hi, x_new, keep = delta_time_bracket(daily, np.datetime64('2006-03-01T06:00:00'))
+    assert len(keep) == 365 and 59 not in keep
+    assert str(daily[keep[ib]])[5:10] == '03-01' and str(daily[keep[ia]])[5:10] == '03-02'
+
+
+def test_regrid_tables_reproduce_oracle_on_cpu():
+    """The index/weight tables + the kernel's formula, evaluated with numpy, equal the oracle."""
+    from pgw4era5_amd import synthetic
+    from pgw4era5_amd.functions import regrid_tables
+    g = synthetic.make_gcm_grid_case(seed=3)
+    for tl in (g['targ_lon'], g['targ_lon'] - 180.0):
+        tb = regrid_tables(g['src_lat'], g['src_lon'], g['targ_lat'], tl)
+        f = g['field']
+        pole_s = np.nanmean(f[..., tb['south_row'], :], axis=-1) if tb['south_row'] >= 0 else None
+        pole_n = np.nanmean(f[..., tb['north_row'], :], axis=-1) if tb['north_row'] >= 0 else None
+
+        def row(r):
+            if r < 0:
+                return np.repeat(pole_s[..., None], f.shape[-1], -1)
+            if r >= f.shape[-2]:
+                return np.repeat(pole_n[..., None], f.shape[-1], -1)
+            return f[..., r, :]
+        out = np.empty(f.shape[:-2] + (len(g['targ_lat']), len(tl)))
+        for j in range(len(g['targ_lat'])):
+            lo, hi = row(tb['lat_lo'][j]), row(tb['lat_hi'][j])
+            a = (hi - lo) / tb['lat_Dx'][j] * tb['lat_dx'][j] + lo
+            ya, yb = a[..., tb['lon_lo']], a[..., tb['lon_hi']]
+            out[..., j, :] = (yb - ya) / tb['lon_Dx'] * tb['lon_dx'] + ya
+        want = O.regrid_lat_lon(f, g['src_lat'], g['src_lon'], g['targ_lat'], tl)
+        np.testing.assert_allclose(out, want, rtol=1e-13, atol=1e-15)
+    with pytest.raises(ValueError) as e:
+        regrid_tables(g['src_lat'][::-1], g['src_lon'], g['targ_lat'], g['targ_lon'])
+    assert 'North or South' in str(e.value)
+    with pytest.raises(ValueError) as e:
+        regrid_tables(g['src_lat'], g['src_lon'][:40], g['targ_lat'], g['targ_lon'])
+    assert 'East or West' in str(e.value)
+
+
+def test_synthetic_files_roundtrip(tmp_path):
+    from pgw4era5_amd import synthetic, ncio
+    case = synthetic.make_case(4, 6, 8, seed=2, dtype=np.float32)
+    path = synthetic.write_case_files(case, str(tmp_path / 'era'), str(tmp_path / 'deltas'))
+    assert os.path.basename(path) == 'cas20060802030000.nc'
+    ds = ncio.open_dataset(path, decode_times=False)
+    np.testing.assert_array_equal(ds['T'].values, case['era']['T'])
+    assert ds['T'].dims == ('time', 'level', 'lat', 'lon') and ds['T'].dtype == np.float32
+    dd = ncio.open_dataset(str(tmp_path / 'deltas' / 'ta_delta.nc'))
+    np.testing.assert_array_equal(dd['time'].values, case['delta_times'])
+    np.testing.assert_array_equal(dd['plev'].values, case['plev'])
+    assert os.path.exists(tmp_path / 'deltas' / 'ps_historical.nc')
+
+
+def _task(x, k):
+    return (x * k, int(os.environ.get('RANK', os.environ.get('PGW_RANK', '0'))))
+
+
+def test_itermp_serial_and_sharding():
+    from pgw4era5_amd.parallel import IterMP, shard_indices
+    assert shard_indices(7, 1, 3) == [1, 4]
+    assert sorted(sum((shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))
+    imp = IterMP(njobs=1)
+    imp.run(_task, dict(k=3), [dict(x=i) for i in range(5)])
+    assert [o[0] for o in imp.output] == [0, 3, 6, 9, 12]
+
+
+def test_itermp_spawned_workers():
+    from pgw4era5_amd.parallel import IterMP
+    imp = IterMP(njobs=2)
+    imp.run(_task, dict(k=2), [dict(x=i) for i in range(5)])
+    assert [o[0] for o in imp.output] == [0, 2, 4, 6, 8]
+    assert [o[1] for o in imp.output] == [0, 1, 0, 1, 0]          # round-robin deal
+
+
+GLOO_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+from pgw4era5_amd.parallel import IterMP
+def task(x, k):
+    return [x * k, int(os.environ['RANK'])]
+imp = IterMP(njobs=2, backend='gloo')
+imp.run(task, dict(k=5), [dict(x=i) for i in range(7)])
+if int(os.environ['RANK']) == 0:
+    print('RESULT ' + json.dumps(imp.output))
+'''
+
+
+def test_itermp_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(GLOO_SCRIPT % ROOT)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29517', str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')][0]
+    import json
+    out = json.loads(line[7:])
+    assert [o[0] for o in out] == [0, 5, 10, 15, 20, 25, 30]
+    assert [o[1] for o in out] == [0, 1, 0, 1, 0, 1, 0]
+
+
+def test_cli_argument_surface():
+    from pgw4era5_amd import step_03_apply_to_era as s3, step_02_preproc_deltas as s2
+    with pytest.raises(ValueError) as e:
+        s3._cli(['-o', 'x', '-d', 'y'])
+    assert str(e.value) == 'Input directory (-i) is required.'
+    with pytest.raises(ValueError) as e:
+        s3._cli(['-i', 'x', '-o', 'y', '-d', 'z', '-D', 'bogus'])
+    assert 'Invalid input for argument --debug_mode' in str(e.value)
+    with pytest.raises(ValueError) as e:
+        s2.main(['regridding', '-i', 'a', '-o', 'b'])
+    assert str(e.value) == 'era5_file_path is required for regridding step.'
+    with pytest.raises(SystemExit):
+        s2.main(['frobnicate'])
