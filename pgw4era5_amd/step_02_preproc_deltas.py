@@ -42,6 +42,8 @@ def main(argv=None):
     done = []
     for var_name in var_names:
         print(var_name)
+        if var_name in ('tos', 'siconc'):
+            interp_wrapper(None, ds_era5, var_name)      # raises: ocean-grid scheme is out of scope
         for clim_period in ['HIST', 'SCEN-HIST']:
             fname = file_name_bases[clim_period].format(var_name)
             inp, out = os.path.join(args.input_dir, fname), os.path.join(args.output_dir, fname)
