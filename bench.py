@@ -43,6 +43,8 @@ def parse():
     p.add_argument('--nlev', type=int, default=137)
     p.add_argument('--cpu-rows', type=int, default=160, help='latitude rows of the CPU-baseline sample')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--overlap-streams', type=int, default=2,
+                   help='extra (untimed-for-value) region with this many files in flight per GPU on separate HIP streams; 0 = skip')
     p.add_argument('--full-column', action='store_true',
                    help='pass kernel reads every level (input-independent traffic) instead of stopping above p_ref')
     return p.parse_args()
@@ -55,6 +57,13 @@ def kernel_bytes(name, N, S, ncol, s, info):
     if name == 'adjust_ps_step':      # ta, e per level read; PS,FIS (storage) + 6 fp64 state words
         lv = info.get('levels_per_launch', N * ncol)
         return 2 * lv * s + ncol * (2 * s + 6 * 8)
+    if name == 'thermo_delta':        # T, QV in; T_pgw, e out; 2 records x S for ta and hur; 7 2-D fields
+        return (4 * N + 4 * S + 7) * ncol * s
+    if name == 'wind_delta':          # U, V in; U_pgw, V_pgw out; 2 records x S for ua and va; PS
+        return (4 * N + 4 * S + 1) * ncol * s
+    if name == 'phi_ref_hybrid':      # T, QV below p_ref; PS, FIS in; phi_ref (fp64) out
+        lv = info.get('levels_per_launch', N * ncol)
+        return 2 * lv * s + ncol * (2 * s + 8)
     if name == 'vert_interp_delta':   # 2 records x S, add_to N in, N out, ps + surface pairs
         return (2 * S + 2 * N) * ncol * s + 5 * ncol * s
     if name == 'q_to_rh':             # QV, T in, RH out, PS
@@ -120,8 +129,11 @@ def main():
         infos.append(info)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {k: ctx.profile_get(k) for k in ('integ_geopot', 'adjust_ps_step', 'vert_interp_delta', 'q_to_rh',
-                                            'rh_to_q', 'finalize', 'pressure', 'time_lerp', 'surface')}
+    prof = {k: ctx.profile_get(k) for k in ('thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'finalize',
+                                            'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q',
+                                            'pressure', 'time_lerp')}
+    micro = microbench(ctx, era, coeffs, a, np) if rank == 0 else {}
+    overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a) if (rank == 0 and a.overlap_streams > 1) else None
     ctx.profile(False)
     if dist is not None:
         import torch
@@ -164,6 +176,8 @@ def main():
                        'mean_levels_read_per_column_per_pass': round(lv_per_launch / ncol, 2)},
             'roofline': roof,
             'kernels': kern,
+            'signature_kernels': micro,
+            'overlap': overlap,
             'device': ctx.device_name(),
             'setup_s': round(t_gen, 1),
         }
@@ -175,10 +189,93 @@ def main():
         dist.destroy_process_group()
 
 
+def overlap_region(device, era, coeffs, deltas, stamps, a):
+    """Same K files, but `--overlap-streams` files in flight per GPU: one host thread + one
+    pgw_ctx (HIP stream, workspaces, outputs) per in-flight file, so the fp64-VALU-bound delta
+    kernels of one file overlap the HBM-bound loop / finalize kernels of another and the host-side
+    status reads of one stream hide behind the other's kernels.  Reported beside `value`, not as it
+    (per-kernel event timings of overlapped kernels would not be clean roofline inputs)."""
+    import threading
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import Context
+    n = a.overlap_streams
+    ctxs = [Context(device) for _ in range(n)]
+    outs = [{} for _ in range(n)]
+    dsets = []
+    for c in ctxs:                     # same device arrays, other context (arrays are plain device pointers)
+        d = s3.DeltaSet.__new__(s3.DeltaSet)
+        d.__dict__.update(deltas.__dict__)
+        d.ctx = c
+        dsets.append(d)
+    for i, c in enumerate(ctxs):       # warm-up: workspaces + level tables of every context
+        s3.process_file_device(c, era, coeffs, dsets[i], stamps[0], True, out=outs[i])
+        c.sync()
+    errs = []
+
+    def work(i):
+        try:
+            for k in range(i, len(stamps), n):
+                s3.process_file_device(ctxs[i], era, coeffs, dsets[i], stamps[k], True, out=outs[i])
+            ctxs[i].sync()
+        except Exception as e:        # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    for o in outs:
+        for v in o.values():
+            v.free()
+    for c in ctxs:
+        c.close()
+    if errs:
+        return {'error': errs[0]}
+    return {'streams': n, 'files': len(stamps), 'ms_per_file': round(el / len(stamps) * 1e3, 3),
+            'files_per_hour_per_gpu': round(len(stamps) / el * 3600.0, 1)}
+
+
+def microbench(ctx, era, coeffs, a, np, reps=5):
+    """Signature-faithful kernels of SURVEY.md section 8(a) that the fused file path no longer
+    launches, timed on the same device arrays outside the timed region: `integ_geopot`
+    (functions.py:128-189, full column - the kernel BASELINE.json's metric names) and the
+    hybrid-pressure kernel ("integ_pressure", step_03:64-88)."""
+    from pgw4era5_amd.device import dtype_tag
+    dt = era['T'].dtype
+    s = dt.itemsize
+    nt, N, nlat, nlon = era['T'].shape
+    ncol = nlat * nlon
+    tag = dtype_tag(dt)
+    ctx.set_levels(coeffs['ak'], coeffs['bk'])
+    pa_hl = ctx.empty((nt, N + 1, nlat, nlon), dt)
+    pa = ctx.empty((nt, N, nlat, nlon), dt)
+    phi = ctx.empty((nt, nlat, nlon), dt)
+    out = {}
+    ctx.profile(True)
+    ctx.profile_reset()
+    for _ in range(reps + 1):
+        ctx._check(ctx.lib.pgw_pressure_levels(ctx.handle, tag, nt, ncol, era['PS'].ptr, pa_hl.ptr, pa.ptr))
+        ctx._check(ctx.lib.pgw_integ_geopot(ctx.handle, tag, nt, N, ncol, pa_hl.ptr, era['FIS'].ptr, era['T'].ptr,
+                                            era['QV'].ptr, 30000.0, None, phi.ptr, 1))
+    for name, nbytes in (('integ_geopot', (3 * N + 3) * ncol * s), ('pressure', (2 * N + 2) * ncol * s)):
+        cnt, ms = ctx.profile_get(name)
+        avg = ms / cnt
+        out[name] = dict(launches=cnt, avg_ms=round(avg, 4), algo_GB=round(nbytes / 1e9, 4),
+                         GBps=round(nbytes / 1e9 / (avg / 1e3), 1), frac_of_peak=round(nbytes / 1e9 / (avg / 1e3) / HBM_PEAK_GBS, 4))
+    ctx.profile(False)
+    ctx.profile_reset()
+    for x in (pa_hl, pa, phi):
+        x.free()
+    return out
+
+
 PMC_KERNEL = {'integ_geopot': 'k_integ_geopot', 'adjust_ps_step': 'k_adjust_ps_step',
               'vert_interp_delta': 'k_vert_interp_delta', 'q_to_rh': 'k_humidity_hybrid', 'rh_to_q': 'k_humidity_hybrid',
-              'finalize': 'k_finalize_ps_hus', 'pressure': 'k_pressure_levels', 'thermo_delta': 'k_thermo_delta',
-              'wind_delta': 'k_wind_delta'}
+              'finalize': 'k_finalize_ps_hus', 'pressure': 'k_pressure_levels',
+              'thermo_delta': 'k_delta_pair<double, 2, true>', 'wind_delta': 'k_delta_pair<double, 2, false>',
+              'phi_ref_hybrid': 'k_phi_ref_hybrid'}
 
 
 def pmc_traffic(kernel, a):
@@ -194,8 +291,12 @@ def pmc_traffic(kernel, a):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    vals = [v['hbm_bytes_per_launch'] for k, v in d.items()
-            if k.startswith(PMC_KERNEL.get(kernel, '?')) and 'hbm_bytes_per_launch' in v]
+    pat = PMC_KERNEL.get(kernel, '?')
+    if 'k_delta_pair' in pat:
+        match = lambda k: k.startswith('k_delta_pair') and k.endswith(pat.split(', ')[-1])
+    else:
+        match = lambda k: k.startswith(pat)
+    vals = [v['hbm_bytes_per_launch'] for k, v in d.items() if match(k) and 'hbm_bytes_per_launch' in v]
     if not vals:
         return None, None
     return round(sum(vals) / len(vals) / 1e9, 4), os.path.relpath(files[-1], ROOT)

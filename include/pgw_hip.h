@@ -59,7 +59,8 @@ enum pgw_kernel_id {
     PGW_K_PRESSURE = 0, PGW_K_Q_TO_RH = 1, PGW_K_RH_TO_Q = 2, PGW_K_INTEG_GEOPOT = 3,
     PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
     PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
-    PGW_K_COUNT = 11
+    PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13,
+    PGW_K_COUNT = 14
 };
 
 /* ---------------------------------------------------------------- context ------------ */
@@ -211,6 +212,47 @@ int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
  * (the pass kernel stops a wave above p_ref); used for the bytes-moved accounting. */
 unsigned long long pgw_last_levels_touched(pgw_ctx *ctx);
 
+/* ---------------------------------------------------------------- whole file ---------- */
+/* The per-file compute path of pgw_for_era5 (reference step_03_apply_to_era.py:62-346 with
+ * i_reinterp = 0 and a fixed p_ref) as ONE call on device-resident arrays, using fused kernels:
+ *   ta+hur: RELHUM of the ERA state (:91-94), both delta interpolations incl. surface insertion
+ *           (functions.py:306-431), the add (:170-173) and e = hur_pgw/100*e_sat(ta_pgw)
+ *           (functions.py:123) in one pass over T, QV;
+ *   ua+va : both delta interpolations + add in one pass over U, V;
+ *   phi_ref of the ERA state from (T, QV, PS, FIS) without a 4-D pressure array (:280-287);
+ *   the fixed-point loop (:182-319) and the final PS / QV (:193, :262-266, :369-371);
+ *   the surface riders (:103-146).
+ * All field pointers are device pointers in storage `dtype`; delta records are the two
+ * bracketing time records (`*_a` may be NULL / x_hi == 0 for an exact hit, functions.py:282-283).
+ * Results are identical to calling the function-level entry points in the reference's order. */
+typedef struct pgw_file_args {
+    /* shapes */
+    int dtype, ntime, nlev, nplev, nsoil, ignore_top, max_n_iter, _pad0;
+    long long ncol;
+    /* ERA5 file (device) + small host tables */
+    const void *PS, *FIS, *T, *QV, *U, *V;                  /* (ntime,ncol) / (ntime,nlev,ncol)   */
+    const void *T_SKIN, *T_SO, *FR_LAND, *FR_SEA_ICE;       /* surface riders, NULL to skip them  */
+    const double *soil_depth;                               /* host, nsoil                        */
+    const double *plev;                                     /* host, nplev, file order            */
+    /* delta records (device) */
+    const void *ta_b, *ta_a, *hur_b, *hur_a, *ua_b, *ua_a, *va_b, *va_a;   /* (ntime,nplev,ncol) */
+    const void *zg_b, *zg_a;                                /* (ntime,ncol): zg delta at plev == p_ref */
+    const void *tas_b, *tas_a, *hurs_b, *hurs_a, *pshist_b, *pshist_a;     /* (ntime,ncol)       */
+    const void *siconc_b, *siconc_a, *ts_b, *ts_a, *tos_b, *tos_a, *ts_clim;
+    double x_hi, x_new;                                     /* time-lerp abscissae (pgw_time_lerp) */
+    /* loop controls (settings.py:140-150 of the reference) */
+    double p_ref, adj_factor, thresh;
+    /* outputs (device); T_out..V_out (ntime,nlev,ncol); hur_pgw_out optional (may be NULL) */
+    void *PS_out, *T_out, *QV_out, *U_out, *V_out, *hur_pgw_out;
+    void *T_SKIN_out, *T_SO_out, *FR_SEA_ICE_out;
+    /* results */
+    int n_iter, _pad1;
+    unsigned long long levels_touched;
+    double max_err_hist[32];
+} pgw_file_args;
+
+int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *args);
+
 /* ---------------------------------------------------------------- step_02 regridding - */
 /* a10 regrid_lat_lon, xarray branch (functions.py:774-789, 817-893): separable linear
  * interpolation, latitude first then longitude, on tables the host derives from the
@@ -239,6 +281,10 @@ int pgw_surface_update(pgw_ctx *ctx, int dtype, int ntime, long long ncol, int n
                        const void *sic, const void *dsic, const void *dtos, const void *dts,
                        const void *land, const void *ts_clim, const void *tskin, const void *tso,
                        void *sic_out, void *dts_comb_out, void *tskin_out, void *tso_out);
+
+/* diagnostic: out[i] = ln(in[i]) with the device logarithm every kernel uses (pgw_device.h
+ * pgw_log: fdlibm log kernel for positive normal finite x, ocml log otherwise); device fp64 arrays */
+int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out);
 
 /* integrate_tos(tos_field, ts_field, land_frac, ice_frac)  functions.py:1145-1186, flat over n */
 int pgw_integrate_tos(pgw_ctx *ctx, int dtype, long long n, const void *tos, const void *ts,

@@ -22,7 +22,8 @@ LIB_PATH = os.path.join(_HERE, 'libpgw_hip.so')
 PGW_F32, PGW_F64 = 0, 1
 EXTRAP = {'off': 0, 'linear': 1, 'constant': 2, 'nan': 3}
 KERNEL_IDS = dict(pressure=0, q_to_rh=1, rh_to_q=2, integ_geopot=3, interp_logp=4, time_lerp=5,
-                  vert_interp_delta=6, adjust_ps_step=7, regrid=8, surface=9, finalize=10)
+                  vert_interp_delta=6, adjust_ps_step=7, regrid=8, surface=9, finalize=10,
+                  thermo_delta=11, wind_delta=12, phi_ref_hybrid=13)
 
 PGW_OK = 0
 PGW_ERR_HIP = 1
@@ -81,6 +82,28 @@ SIGNATURES = {
     'pgw_surface_update': (_i, [_vp, _i, _i, _ll, _i, _dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
 }
+
+
+
+class FileArgs(C.Structure):
+    """`pgw_file_args` of include/pgw_hip.h (whole-file entry pgw_step03_file)."""
+    _fields_ = (
+        [(n, C.c_int) for n in ('dtype', 'ntime', 'nlev', 'nplev', 'nsoil', 'ignore_top', 'max_n_iter', '_pad0')] +
+        [('ncol', C.c_longlong)] +
+        [(n, C.c_void_p) for n in ('PS', 'FIS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE')] +
+        [('soil_depth', _dp), ('plev', _dp)] +
+        [(n, C.c_void_p) for n in ('ta_b', 'ta_a', 'hur_b', 'hur_a', 'ua_b', 'ua_a', 'va_b', 'va_a', 'zg_b', 'zg_a',
+                                   'tas_b', 'tas_a', 'hurs_b', 'hurs_a', 'pshist_b', 'pshist_a',
+                                   'siconc_b', 'siconc_a', 'ts_b', 'ts_a', 'tos_b', 'tos_a', 'ts_clim')] +
+        [(n, C.c_double) for n in ('x_hi', 'x_new', 'p_ref', 'adj_factor', 'thresh')] +
+        [(n, C.c_void_p) for n in ('PS_out', 'T_out', 'QV_out', 'U_out', 'V_out', 'hur_pgw_out',
+                                   'T_SKIN_out', 'T_SO_out', 'FR_SEA_ICE_out')] +
+        [('n_iter', C.c_int), ('_pad1', C.c_int), ('levels_touched', C.c_ulonglong),
+         ('max_err_hist', C.c_double * 32)])
+
+
+SIGNATURES['pgw_step03_file'] = (_i, [_vp, C.POINTER(FileArgs)])
+SIGNATURES['pgw_test_log'] = (_i, [_vp, _ll, _vp, _vp])
 
 _lib = None
 

@@ -123,10 +123,14 @@ static inline unsigned int nblocks(long long n, int per) { return (unsigned int)
 static inline bool aligned16(const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
 
 // columns per thread: 16 B per lane when shape and alignment allow, else 1
-static int pick_vec(int dtype, long long ncol, std::initializer_list<const void *> ptrs) {
+// `max_v` caps the width for kernels whose register footprint makes the widest form slower.
+static int pick_vec(int dtype, long long ncol, std::initializer_list<const void *> ptrs, int max_v = 4) {
     int v = (dtype == PGW_F64) ? 2 : 4;
-    if (ncol % v != 0) return 1;
+    if (v > max_v) v = max_v;
+    static const char *force = getenv("PGW_FORCE_VEC1");       // tuning knob: scalar columns per thread
+    if (force && force[0] == '1') return 1;
     for (const void *p : ptrs) if (!aligned16(p)) return 1;
+    while (v > 1 && ncol % v != 0) v >>= 1;
     return v;
 }
 
@@ -376,7 +380,9 @@ extern "C" int pgw_get_full_level_coeffs(pgw_ctx *ctx, double *akm_out, double *
             if (vec == 2) { constexpr int V = 2; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
         } else {                                                            \
             typedef float T;                                                \
-            if (vec == 4) { constexpr int V = 4; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+            if (vec == 4) { constexpr int V = 4; __VA_ARGS__; }             \
+            else if (vec == 2) { constexpr int V = 2; __VA_ARGS__; }        \
+            else { constexpr int V = 1; __VA_ARGS__; }                      \
         }                                                                   \
     } while (0)
 
@@ -659,18 +665,44 @@ extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int npl
 }
 
 // ------------------------------------------------------------------ ps fixed-point loop
+#ifndef STEP_U
+#define STEP_U 4
+#endif
+static int step_u() {
+    static const char *e = getenv("PGW_STEP_U");      // tuning knob: levels per pipelined chunk of the pass kernel
+    return (e && e[0] == '2') ? 2 : STEP_U;
+}
+
 static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *evap,
                        const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
                        double *delta_ps, double *adj_ps, double p_ref, const double *p_ref_field,
                        double adj_factor, int full_column) {
-    int vec = pick_vec(dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field});
+    int vec = pick_vec(dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field}, 2);
     // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_ADJUST_PS_STEP);
-    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
-                                                (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                p_ref, p_ref_field, adj_factor, full_column, ctx->d_status));
+    if (step_u() == 2)
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, 2>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                    dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
+                                                    (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
+                                                    p_ref, p_ref_field, adj_factor, full_column, ctx->d_status));
+    else
+        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                    dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
+                                                    (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
+                                                    p_ref, p_ref_field, adj_factor, full_column, ctx->d_status));
+    return PGW_OK;
+}
+
+static int launch_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *hus,
+                                 const void *PS, const void *FIS, double p_ref, double *phi_out, int full_column) {
+    int vec = pick_vec(dtype, ncol, {ta, hus, PS, FIS, phi_out}, 2);
+    Levels lv = levels_of(ctx);
+    Prof pr(ctx, PGW_K_PHI_REF_HYBRID);
+    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_phi_ref_hybrid<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)hus,
+                                                (const T *)PS, (const T *)FIS, p_ref, (const double *)nullptr, phi_out,
+                                                full_column, ctx->d_status));
     return PGW_OK;
 }
 
@@ -680,6 +712,11 @@ static double max_err_of(pgw_ctx *ctx) {
     double m;
     memcpy(&m, &h->max_bits, 8);
     return m;
+}
+
+static int pair_vec_env() {
+    static const char *e = getenv("PGW_PAIR_VEC");     // tuning knob: 16 B per lane in the delta-pair kernels
+    return (e && e[0] == '1') ? 1 : 0;
 }
 
 static int full_column_env() {
@@ -710,38 +747,32 @@ extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long 
     return rc;
 }
 
-extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *PS,
-                                  const void *FIS, const void *T, const void *QV, const void *ta_pgw,
-                                  const void *hur_pgw, const void *dzg_pref, double p_ref, double adj_factor,
-                                  double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
-                                  double *max_err_hist) {
-    CHECK_COMMON(ctx, dtype, ntime, ncol);
-    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
-    NEED(ctx, PS && FIS && T && QV && ta_pgw && hur_pgw && dzg_pref, "null pointer");
-    const int N = ctx->nlev;
+// The loop of step_03_apply_to_era.py:182-319 given the iterate-independent vapour pressure
+// `evap` = hur_pgw/100 * e_sat(ta_pgw) (functions.py:123).  Shared by pgw_adjust_ps_loop and
+// pgw_step03_file.
+static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *PS, const void *FIS,
+                       const void *T, const void *QV, const void *ta_pgw, const void *evap,
+                       const void *dzg_b, const void *dzg_a, double x_hi, double x_new, double p_ref,
+                       double adj_factor, double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
+                       double *max_err_hist, int hist_len) {
     const long long n2 = (long long)ntime * ncol;
-    const size_t es = dtype == PGW_F64 ? 8 : 4;
-    void *evap = nullptr, *state = nullptr, *pahl = nullptr;
+    void *state = nullptr;
     int rc;
-    if ((rc = ws_get(ctx, 0, (size_t)ntime * N * ncol * es, &evap))) return rc;
     if ((rc = ws_get(ctx, 1, (size_t)n2 * 4 * sizeof(double), &state))) return rc;
-    if ((rc = ws_get(ctx, 2, (size_t)ntime * (N + 1) * ncol * es, &pahl))) return rc;
     double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
     const int full_column = full_column_env();
 
     // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it)
-    if ((rc = pgw_pressure_levels(ctx, dtype, ntime, ncol, PS, pahl, nullptr))) return rc;
     if ((rc = status_reset(ctx))) return rc;
-    launch_integ_geopot(ctx, dtype, N, ntime, ncol, pahl, FIS, T, QV, p_ref, nullptr, phi_era, 1, true);
+    launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column);
     HIPCHK(ctx, hipGetLastError());
     if ((rc = status_check(ctx))) return rc;
+    // g * (time-interpolated zg delta at p_ref)   step_03:292-295
     DISPATCH_T(dtype, {
-        hipLaunchKernelGGL((k_scale_to_f64<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, (const T *)dzg_pref,
-                           CON_G, dphi);                                   // step_03:292-293
+        DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
+        hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi);
     });
     HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
-    // e = hur_pgw/100 * e_sat(ta_pgw): iterate-independent part of :262-266
-    if ((rc = humidity_hybrid<2>(ctx, PGW_K_RH_TO_Q, dtype, ntime, ncol, hur_pgw, PS, ta_pgw, evap))) return rc;
 
     double phi_ref_max_error = INFINITY;                                   // :186
     int it = 1;                                                            // :188
@@ -754,7 +785,7 @@ extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long 
         if ((rc = status_check(ctx))) return rc;
         phi_ref_max_error = max_err_of(ctx);                               // :308
         touched += ctx->h_status->levels_touched;
-        if (max_err_hist && it - 1 < max_n_iter) max_err_hist[it - 1] = phi_ref_max_error;
+        if (max_err_hist && it - 1 < hist_len) max_err_hist[it - 1] = phi_ref_max_error;
         it += 1;                                                           // :313
         if (it > max_n_iter) {                                             // :315-319
             if (n_iter) *n_iter = it - 1;
@@ -777,7 +808,142 @@ extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long 
     return PGW_OK;
 }
 
+extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *PS,
+                                  const void *FIS, const void *T, const void *QV, const void *ta_pgw,
+                                  const void *hur_pgw, const void *dzg_pref, double p_ref, double adj_factor,
+                                  double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
+                                  double *max_err_hist) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, PS && FIS && T && QV && ta_pgw && hur_pgw && dzg_pref, "null pointer");
+    const size_t es = dtype == PGW_F64 ? 8 : 4;
+    void *evap = nullptr;
+    int rc;
+    if ((rc = ws_get(ctx, 0, (size_t)ntime * ctx->nlev * ncol * es, &evap))) return rc;
+    // e = hur_pgw/100 * e_sat(ta_pgw): iterate-independent part of :262-266
+    if ((rc = humidity_hybrid<2>(ctx, PGW_K_RH_TO_Q, dtype, ntime, ncol, hur_pgw, PS, ta_pgw, evap))) return rc;
+    return run_ps_loop(ctx, dtype, ntime, ncol, PS, FIS, T, QV, ta_pgw, evap, dzg_pref, nullptr, 0.0, 0.0, p_ref,
+                       adj_factor, thresh, max_n_iter, ps_pgw, hus_pgw, n_iter, max_err_hist, max_n_iter);
+}
+
+// ------------------------------------------------------------------ whole file
+extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
+    NEED(ctx, a != nullptr, "null args");
+    const int dtype = a->dtype, ntime = a->ntime;
+    const long long ncol = a->ncol;
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0 && a->nlev == ctx->nlev, "nlev must match pgw_set_levels");
+    NEED(ctx, a->nplev >= 2 && a->nplev <= MAX_PLEV, "nplev must be in [2, 64]");
+    NEED(ctx, a->PS && a->FIS && a->T && a->QV && a->U && a->V, "ERA5 field pointer is NULL");
+    NEED(ctx, a->plev && a->ta_b && a->hur_b && a->ua_b && a->va_b && a->zg_b && a->tas_b && a->hurs_b && a->pshist_b,
+         "delta record pointer is NULL");
+    NEED(ctx, a->PS_out && a->T_out && a->QV_out && a->U_out && a->V_out, "output pointer is NULL");
+    NEED(ctx, a->max_n_iter >= 1 && a->max_n_iter <= 1000, "bad max_n_iter");
+    const bool exact = (a->x_hi == 0.0);
+    const size_t es = dtype == PGW_F64 ? 8 : 4;
+    const int N = a->nlev;
+    int rc;
+    if ((rc = plev_table(ctx, a->nplev, a->plev))) return rc;
+    void *evap = nullptr;
+    if ((rc = ws_get(ctx, 0, (size_t)ntime * N * ncol * es, &evap))) return rc;
+    Levels lv = levels_of(ctx);
+    const int check_top = a->ignore_top ? 0 : 1;
+    auto top_check = [&]() -> int {                       // functions.py:417-425
+        if (!check_top) return PGW_OK;
+        DevStatus *h = ctx->h_status;
+        if (!h->nan_seen && h->min_targ_bits != ~0ull && h->min_src_bits != ~0ull) {
+            double mt, ms;
+            memcpy(&mt, &h->min_targ_bits, 8);
+            memcpy(&ms, &h->min_src_bits, 8);
+            if (mt < ms) { ctx->err = status_text(PGW_ERR_TOP_PRESSURE); ctx->err_col = -1; return PGW_ERR_TOP_PRESSURE; }
+        }
+        return PGW_OK;
+    };
+
+    // ---- surface riders (step_03:103-146)
+    if (a->FR_SEA_ICE && a->siconc_b && a->FR_SEA_ICE_out) {
+        NEED(ctx, a->ts_b && a->tos_b && a->FR_LAND && a->T_SKIN && a->T_SKIN_out, "surface rider pointer is NULL");
+        NEED(ctx, a->nsoil >= 0 && a->nsoil <= MAX_SOIL, "nsoil must be in [0, 16]");
+        NEED(ctx, a->nsoil == 0 || (a->T_SO && a->T_SO_out && a->ts_clim && a->soil_depth), "soil pointers missing");
+        SoilTable st;
+        memset(&st, 0, sizeof(st));
+        st.n = a->nsoil;
+        for (int s = 0; s < a->nsoil; ++s) st.w[s] = exp(-a->soil_depth[s] / 2.8);      // step_03:140
+        long long n = (long long)ntime * ncol;
+        Prof pr(ctx, PGW_K_SURFACE);
+        DISPATCH_T(dtype, {
+            DeltaSrc<T> dsic{(const T *)a->siconc_b, exact ? nullptr : (const T *)a->siconc_a, a->x_hi, a->x_new};
+            DeltaSrc<T> dts{(const T *)a->ts_b, exact ? nullptr : (const T *)a->ts_a, a->x_hi, a->x_new};
+            DeltaSrc<T> dtos{(const T *)a->tos_b, exact ? nullptr : (const T *)a->tos_a, a->x_hi, a->x_new};
+            hipLaunchKernelGGL((k_surface_update_lerp<T>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, ntime, ncol, st,
+                               (const T *)a->FR_SEA_ICE, dsic, dtos, dts, (const T *)a->FR_LAND, (const T *)a->ts_clim,
+                               (const T *)a->T_SKIN, (const T *)a->T_SO, (T *)a->FR_SEA_ICE_out, (T *)a->T_SKIN_out,
+                               (T *)a->T_SO_out);
+        });
+    }
+
+    // ---- ta + hur -> T_pgw, e_pgw   and   ua + va -> U_pgw, V_pgw
+    {
+        // the pair kernels are fp64-VALU bound, not HBM bound: one column per thread keeps the VGPR count at
+        // 131 (3 waves/SIMD) and measured 20-25 % faster than 16 B per lane (169 VGPRs, 2 waves/SIMD)
+        int vec = pair_vec_env() ? pick_vec(dtype, ncol, {a->T, a->QV, a->U, a->V, a->PS, a->T_out, a->U_out, a->V_out, evap,
+                                                           a->hur_pgw_out, a->ta_b, a->hur_b, a->ua_b, a->va_b})
+                                 : 1;
+        if ((rc = status_reset(ctx))) return rc;
+        {
+            Prof pr(ctx, PGW_K_THERMO_DELTA);
+            DISPATCH_TV(dtype, vec, {
+                PairSrc<T> d3{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
+                              {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
+                PairSrc<T> ds{{(const T *)a->tas_b, exact ? nullptr : (const T *)a->tas_a, a->x_hi, a->x_new},
+                              {(const T *)a->hurs_b, exact ? nullptr : (const T *)a->hurs_a, a->x_hi, a->x_new}};
+                DeltaSrc<T> ph{(const T *)a->pshist_b, exact ? nullptr : (const T *)a->pshist_a, a->x_hi, a->x_new};
+                hipLaunchKernelGGL((k_delta_pair<T, V, true>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)), dim3(BLOCK), 0,
+                                   ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV, (const T *)a->PS,
+                                   d3, ds, ph, check_top, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, ctx->d_status);
+            });
+        }
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = status_check(ctx))) return rc;
+        if ((rc = top_check())) return rc;
+        if ((rc = status_reset(ctx))) return rc;
+        {
+            Prof pr(ctx, PGW_K_WIND_DELTA);
+            DISPATCH_TV(dtype, vec, {
+                PairSrc<T> d3{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
+                              {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
+                PairSrc<T> ds{{nullptr, nullptr, 0.0, 0.0}, {nullptr, nullptr, 0.0, 0.0}};
+                DeltaSrc<T> ph{nullptr, nullptr, 0.0, 0.0};
+                hipLaunchKernelGGL((k_delta_pair<T, V, false>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)), dim3(BLOCK), 0,
+                                   ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->U, (const T *)a->V, (const T *)a->PS,
+                                   d3, ds, ph, check_top, (T *)a->U_out, (T *)a->V_out, (T *)nullptr, ctx->d_status);
+            });
+        }
+        HIPCHK(ctx, hipGetLastError());
+        if (check_top) {
+            if ((rc = status_check(ctx))) return rc;
+            if ((rc = top_check())) return rc;
+        }
+    }
+
+    // ---- fixed-point loop + final PS, QV
+    a->n_iter = 0;
+    for (int i = 0; i < 32; ++i) a->max_err_hist[i] = NAN;
+    rc = run_ps_loop(ctx, dtype, ntime, ncol, a->PS, a->FIS, a->T, a->QV, a->T_out, evap, a->zg_b, a->zg_a, a->x_hi,
+                     a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
+                     a->max_err_hist, 32);
+    a->levels_touched = ctx->last_levels_touched;
+    return rc;
+}
+
 extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx->last_levels_touched; }
+
+extern "C" int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out) {
+    NEED(ctx, n >= 1 && in && out, "bad argument");
+    hipLaunchKernelGGL(k_test_log, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out);
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
 
 // ------------------------------------------------------------------ regridding
 extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, int nlat_s, int nlon_s, int nlat_t,

@@ -49,6 +49,42 @@ __device__ __forceinline__ void report(DevStatus *st, int code, long long col) {
     atomicCAS(&st->code, 0, code);
 }
 
+// ---- natural logarithm ------------------------------------------------------------------
+// Every kernel on the path takes one ln(p) per level and column, and with fp64 vector math at
+// half rate the generic ocml log (~65 instructions, double-double internals, denormal /
+// negative / inf handling) made the column kernels VALU-bound.  pgw_log is the classic
+// fdlibm __ieee754_log kernel (argument reduction to [sqrt(1/2), sqrt(2)), s = f/(2+f),
+// degree-14 even polynomial; documented error < 1 ulp) for positive normal finite x, with the
+// quotient formed by v_rcp_f64 + two Newton steps + one residual correction; everything else
+// (0, negative, denormal, inf, NaN) goes to the ocml log.  One implementation serves table
+// entries and per-column values, so `src_x == targ_x` comparisons (functions.py:540) are
+// consistent.
+__device__ __forceinline__ double pgw_log(double x) {
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int k = __builtin_amdgcn_frexp_exp(x);                 // x = m * 2^k, m in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    if (m < 0.70710678118654752440) { m = m * 2.0; k -= 1; }
+    double f = m - 1.0;                                    // exact
+    double d = 2.0 + f;                                    // in [1.70, 2.42)
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    double s = f * r;
+    s = __builtin_fma(__builtin_fma(-d, s, f), r, s);      // s = f / (2 + f), correctly rounded up to ~0.5 ulp
+    double dk = (double)k;
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
 // ---- humidity thermodynamics (functions.py:58-125), operation order as written there ----
 __device__ __forceinline__ double esat_water(double ta) {   // :74-89 water
     return 611.21 * exp(17.502 * (ta - 273.16) / (ta - 32.19));

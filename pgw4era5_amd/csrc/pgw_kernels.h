@@ -131,7 +131,7 @@ struct GeoAcc {            // per-column running state of the upward scan
 __device__ __forceinline__ void geo_init(GeoAcc &a, double zgs, double p_bottom) {
     a.phi = zgs;
     a.p_lo = fix_p(p_bottom);
-    a.lnp_lo = log(a.p_lo);
+    a.lnp_lo = pgw_log(a.p_lo);
     a.dmin = __builtin_inf();
     a.kstar = -1;
     a.phi_s = a.tv_s = a.lnp_s = 0.0;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double tv, double p_
         a.dmin = d; a.kstar = l + 1; a.phi_s = a.phi; a.tv_s = tv; a.lnp_s = a.lnp_lo;
     }
     double p_hi = fix_p(p_top);                       // :135
-    double lnp_hi = log(p_hi);
+    double lnp_hi = pgw_log(p_hi);
     a.phi = a.phi + (CON_RD * tv) * (a.lnp_lo - lnp_hi);   // :149-152, dlnpa :136-138
     a.p_lo = p_hi; a.lnp_lo = lnp_hi;
 }
@@ -153,7 +153,7 @@ __device__ __forceinline__ double geo_finish(GeoAcc &a, double p_ref, DevStatus 
     if (d >= 0 && d <= a.dmin) a.kstar = 0;
     if (a.kstar < 0) { report(st, 13 /*PGW_ERR_PREF_BELOW_SURFACE*/, col); return __builtin_nan(""); }
     if (a.kstar == 0) { report(st, 14 /*PGW_ERR_PREF_AT_TOP*/, col); return __builtin_nan(""); }
-    return a.phi_s - (CON_RD * a.tv_s) * (log(p_ref) - a.lnp_s);    // :174-179
+    return a.phi_s - (CON_RD * a.tv_s) * (pgw_log(p_ref) - a.lnp_s);    // :174-179
 }
 
 // TO = type of the phi_ref output (T for the signature-faithful call, double for the loop state)
@@ -233,7 +233,77 @@ done:
 // does q = 0.622 e / (pa - 0.378 e) (:66-72) - the same values the reference recomputes.
 // State (delta_ps, adj_ps) and the constant phi_ref_era / dphi_clim are fp64.
 // =====================================================================================
-template <typename T, int V>
+// Upward scan of V hybrid-pressure columns from the surface to p_ref: shared by the loop pass
+// (second field = vapour pressure e, q = e_to_q(e, pa)) and by phi_ref of the ERA state (second
+// field = QV itself).  Levels are processed in chunks of U with the next chunk's 2*U row loads
+// already in flight (software pipeline; ~2*U KiB per wave outstanding).
+template <typename T, int V, int U, bool SECOND_IS_Q>
+__device__ __forceinline__ void scan_columns(const Levels &lv, long long ncol, const T *__restrict__ pt,
+                                             const T *__restrict__ pe, const double (&ps)[V], const double (&z)[V],
+                                             const double (&pref)[V], int full_column, DevStatus *st, long long c2,
+                                             double (&phi_ref)[V], double (&tlow)[V], int &touched) {
+    const int N = lv.nlev;
+    GeoAcc acc[V];
+    bool mono[V];
+    {
+        double akN = lv.ak[N], bkN = lv.bk[N];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            geo_init(acc[v], z[v], akN + ps[v] * bkN);          // step_03:198
+            mono[v] = ps[v] >= lv.ps_mono_min;                  // false for NaN
+        }
+    }
+    double tn[U][V], en[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int lu = (N - 1 - u) > 0 ? (N - 1 - u) : 0;
+        loadv<T, V>(pt + (long long)lu * ncol, tn[u]);
+        loadv<T, V>(pe + (long long)lu * ncol, en[u]);
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) tlow[v] = tn[0][v];             // ta at the lowest full level, :303
+    for (int l = N - 1; l >= 0; l -= U) {
+        double t[U][V], e[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < V; ++v) { t[u][v] = tn[u][v]; e[u][v] = en[u][v]; }
+        if (l - U >= 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int lu = (l - U - u) > 0 ? (l - U - u) : 0;
+                loadv<T, V>(pt + (long long)lu * ncol, tn[u]);
+                loadv<T, V>(pe + (long long)lu * ncol, en[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int lc = l - u;
+            if (lc >= 0) {
+                double am = lv.akm[lc], bm = lv.bkm[lc], a = lv.ak[lc], b = lv.bk[lc];
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    double q;
+                    if (SECOND_IS_Q) q = e[u][v];
+                    else q = e_to_q(e[u][v], am + ps[v] * bm);      // :196, :262-266
+                    double tv = t[u][v] * (1 + 0.61 * q);           // functions.py:144
+                    geo_layer(acc[v], lc, tv, a + ps[v] * b, pref[v]);
+                }
+                touched += V;
+            }
+        }
+        if (!full_column) {
+            bool above = true;
+#pragma unroll
+            for (int v = 0; v < V; ++v) above = above && mono[v] && (acc[v].p_lo < pref[v]) && (acc[v].kstar >= 0);
+            if (__all(above)) break;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) phi_ref[v] = geo_finish(acc[v], pref[v], st, c2 + v);
+}
+
+template <typename T, int V, int U>
 __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, long long ncol,
                                                           const T *__restrict__ ta, const T *__restrict__ evap,
                                                           const T *__restrict__ PS, const T *__restrict__ FIS,
@@ -252,9 +322,7 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
         ColIdx ix = col_index(g, V, ncol);
         const int N = lv.nlev;
         long long c2 = ix.t * ncol + ix.c;
-        const T *pt = ta + ix.t * N * ncol + ix.c;
-        const T *pe = evap + ix.t * N * ncol + ix.c;
-        double ps0[V], z[V], dps[V], adj[V], ps[V], pref[V], tlow[V];
+        double ps0[V], z[V], dps[V], adj[V], ps[V], pref[V], tlow[V], phi_ref[V];
         loadv<T, V>(PS + c2, ps0);
         loadv<T, V>(FIS + c2, z);
         loadv<double, V>(delta_ps + c2, dps);
@@ -264,50 +332,18 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
 #pragma unroll
             for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
         }
-        GeoAcc acc[V];
-        bool mono[V];
-        {
-            double akN = lv.ak[N], bkN = lv.bk[N];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                dps[v] = dps[v] + adj[v];                       // step_03:192
-                ps[v] = ps0[v] + dps[v];                        // :193
-                geo_init(acc[v], z[v], akN + ps[v] * bkN);      // :198
-                mono[v] = ps[v] >= lv.ps_mono_min;              // false for NaN
-            }
+        for (int v = 0; v < V; ++v) {
+            dps[v] = dps[v] + adj[v];                       // step_03:192
+            ps[v] = ps0[v] + dps[v];                        // :193
         }
         storev<double, V>(delta_ps + c2, dps);
-        double tn[V], en[V];                                    // prefetched next level
-        loadv<T, V>(pt + (long long)(N - 1) * ncol, tn);
-        loadv<T, V>(pe + (long long)(N - 1) * ncol, en);
-#pragma unroll
-        for (int v = 0; v < V; ++v) tlow[v] = tn[v];            // ta_pgw at the lowest full level, :303
-        for (int l = N - 1; l >= 0; --l) {
-            double t[V], e[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) { t[v] = tn[v]; e[v] = en[v]; }
-            if (l > 0) {
-                loadv<T, V>(pt + (long long)(l - 1) * ncol, tn);
-                loadv<T, V>(pe + (long long)(l - 1) * ncol, en);
-            }
-            double am = lv.akm[l], bm = lv.bkm[l], a = lv.ak[l], b = lv.bk[l];
-            bool above = true;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                double pa = am + ps[v] * bm;                    // :196
-                double q = e_to_q(e[v], pa);                    // :262-266
-                double tv = t[v] * (1 + 0.61 * q);              // functions.py:144
-                geo_layer(acc[v], l, tv, a + ps[v] * b, pref[v]);
-                above = above && mono[v] && (acc[v].p_lo < pref[v]) && (acc[v].kstar >= 0);
-            }
-            touched += V;
-            if (!full_column && __all(above)) break;
-        }
+        scan_columns<T, V, U, false>(lv, ncol, ta + ix.t * N * ncol + ix.c, evap + ix.t * N * ncol + ix.c, ps, z, pref,
+                                     full_column, st, c2, phi_ref, tlow, touched);
         double nadj[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            double phi_ref = geo_finish(acc[v], pref[v], st, c2 + v);
-            double err = (phi_ref - phi_ref_era[c2 + v]) - dphi_clim[c2 + v];        // :289,298
+            double err = (phi_ref[v] - phi_ref_era[c2 + v]) - dphi_clim[c2 + v];      // :289,298
             nadj[v] = -adj_factor * ps[v] / (CON_RD * tlow[v]) * err;                 // :301-304
             double ae = fabs(err);
             if (ae == ae) amax = fmax(amax, ae);                                      // :308 skipna
@@ -332,6 +368,35 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
         }
         atomicAdd(&st->levels_touched, tch);
     }
+}
+
+// phi_ref of the ERA state from (T, QV, PS, FIS) with the hybrid pressure rebuilt in registers
+// (step_03:280-287 with pa_hl_era of :64-66): no 4-D pressure array, and like the pass kernel it
+// only reads the levels below p_ref.
+template <typename T, int V, int U>
+__global__ __launch_bounds__(BLOCK) void k_phi_ref_hybrid(Levels lv, int ntime, long long ncol,
+                                                          const T *__restrict__ ta, const T *__restrict__ hus,
+                                                          const T *__restrict__ PS, const T *__restrict__ FIS,
+                                                          double p_ref_s, const double *__restrict__ p_ref_f,
+                                                          double *__restrict__ phi_out, int full_column, DevStatus *st) {
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    if (g >= ngroups) return;
+    ColIdx ix = col_index(g, V, ncol);
+    const int N = lv.nlev;
+    long long c2 = ix.t * ncol + ix.c;
+    double ps[V], z[V], pref[V], tlow[V], phi_ref[V];
+    int touched = 0;
+    loadv<T, V>(PS + c2, ps);
+    loadv<T, V>(FIS + c2, z);
+    if (p_ref_f) loadv<double, V>(p_ref_f + c2, pref);
+    else {
+#pragma unroll
+        for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
+    }
+    scan_columns<T, V, U, true>(lv, ncol, ta + ix.t * N * ncol + ix.c, hus + ix.t * N * ncol + ix.c, ps, z, pref,
+                                full_column, st, c2, phi_ref, tlow, touched);
+    storev<double, V>(phi_out + c2, phi_ref);
 }
 
 // final outputs of the loop: ps_pgw = PS + delta_ps (step_03:193,369), hus_pgw from e (:262-266,370)
@@ -425,21 +490,21 @@ __global__ __launch_bounds__(TPB) void k_interp_logp(int ntime, int S, int N, lo
     const T *pv = var + t * S * ncol + c;
     const T *pp = srcP + t * S * ncol + c;
     for (int s = 0; s < S; ++s) {
-        sx[s * TPB] = logp_in ? (double)pp[(long long)s * ncol] : log((double)pp[(long long)s * ncol]);   // :470
+        sx[s * TPB] = logp_in ? (double)pp[(long long)s * ncol] : pgw_log((double)pp[(long long)s * ncol]);   // :470
         sy[s * TPB] = (double)pv[(long long)s * ncol];
     }
     if (sx[(S - 1) * TPB] < sx[0]) { report(st, 10, flat); }     // :500-501
     const T *pt = trgP + t * N * ncol + c;
     T *po = out + t * N * ncol + c;
     double x_first = (double)pt[0], x_last = (double)pt[(long long)(N - 1) * ncol];
-    if (!logp_in) { x_first = log(x_first); x_last = log(x_last); }
+    if (!logp_in) { x_first = pgw_log(x_first); x_last = pgw_log(x_last); }
     if (x_last < x_first) { report(st, 11, flat); }              // :502-503
     int j = 0;
     double xprev = -__builtin_inf();
 #pragma unroll 4
     for (int l = 0; l < N; ++l) {
         double x = (double)pt[(long long)l * ncol];
-        if (!logp_in) x = log(x);                                // :471
+        if (!logp_in) x = pgw_log(x);                                // :471
         if (!(x >= xprev)) j = 0;                                // restart (descending or NaN)
         while (j < S) {
             double xs = sx[j * TPB];
@@ -538,7 +603,7 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
                 fill_below = true;
             }
             if (bad) { report(st, 15, flat); ksfc = -1; }
-            lnps = log(pshv);
+            lnps = pgw_log(pshv);
         }
         auto srcx = [&](int i) -> double { return (HAS_SFC && i == ksfc) ? lnps : s_lnp[i]; };
         auto srcy = [&](int i) -> double {
@@ -563,7 +628,7 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
         for (int l = 0; l < N; ++l) {
             double p = ptg ? (double)ptg[(long long)l * ncol] : (lv.akm[l] + psv * lv.bkm[l]);
             if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
-            double x = log(p);
+            double x = pgw_log(p);
             if (!(x >= xprev)) j = 0;
             while (j < S) {
                 double xs = srcx(j);
@@ -601,6 +666,190 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
             int nn = s_nan[0];
             for (int i = 1; i < BLOCK / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
             // pressures are compared as ordered bit patterns; negative values (unphysical) map to 0
+            if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
+            if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
+            if (nn) atomicOr(&st->nan_seen, nn);
+        }
+    }
+}
+
+// =====================================================================================
+// Fused per-file delta kernels (production path of pgw_step03_file).
+//
+// k_delta_pair<THERMO=true>:  ta + hur   (step_03:91-94 RELHUM of the ERA state, functions.py:306-431
+//     for both variables incl. replace_delta_sfc, step_03:170-173 add, and the iterate-independent
+//     vapour pressure e = hur_pgw/100 * e_sat(ta_pgw) of functions.py:123) in ONE pass:
+//     reads T, QV (+ S-level delta records), writes T_pgw and e_pgw.  RELHUM / hur_pgw are never
+//     materialised (the reference deletes RELHUM before writing, step_03:373).
+// k_delta_pair<THERMO=false>: ua + va    (no surface insertion): reads U, V, writes U_pgw, V_pgw.
+//
+// Both variables of a pair see the same target ln p and (because tas/hurs share ps_hist) the same
+// modified source axis, so one log and one bracket search per level serve both.
+// V adjacent columns per thread (16 B per lane); level loads are software-pipelined 2 deep.
+// =====================================================================================
+struct ColScan {
+    int ksfc;          // source level moved to ps_hist (-1: none)
+    bool fill;         // levels below ksfc take the surface delta too
+    double lnps;       // ln(ps_hist)
+    int j;             // current "first source index with sx >= x"
+    double xprev;
+    int ci;            // cached bracket: values of source levels ci, ci+1
+};
+
+template <typename T>
+struct PairSrc {       // the two variables of a pair
+    DeltaSrc<T> a, b;
+};
+
+template <typename T, int V, bool THERMO>
+__global__ __launch_bounds__(BLOCK) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
+                                                      const T *__restrict__ fa, const T *__restrict__ fb,
+                                                      const T *__restrict__ PS,
+                                                      PairSrc<T> d3, PairSrc<T> dsfc, DeltaSrc<T> psh,
+                                                      int check_top, T *__restrict__ out_a, T *__restrict__ out_b,
+                                                      T *__restrict__ out_hur, DevStatus *st) {
+    __shared__ double s_mint[BLOCK / 64], s_mins[BLOCK / 64];
+    __shared__ int s_nan[BLOCK / 64];
+    __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
+    const int S = pt.n;
+    if (threadIdx.x < MAX_PLEV) {
+        s_p[threadIdx.x] = pt.p[threadIdx.x];
+        s_lnp[threadIdx.x] = pt.lnp[threadIdx.x];
+    }
+    __syncthreads();
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = (long long)ntime * ncol / V;
+    double min_t = __builtin_inf(), min_s = __builtin_inf();
+    int nanflag = 0;
+    if (g < ngroups) {
+        ColIdx ix = col_index(g, V, ncol);
+        const int N = lv.nlev;
+        long long c2 = ix.t * ncol + ix.c;
+        long long dbase = ix.t * S * ncol + ix.c;     // delta records (ntime, S, ncol), file order
+        long long base = ix.t * N * ncol + ix.c;
+        double ps[V];
+        loadv<T, V>(PS + c2, ps);
+        ColScan sc[V];
+        double sfa[V], sfb[V];                        // surface deltas of the two variables
+        double ya_lo[V], ya_hi[V], yb_lo[V], yb_hi[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            sc[v].ksfc = -1; sc[v].fill = false; sc[v].lnps = 0.0; sc[v].j = 0;
+            sc[v].xprev = -__builtin_inf(); sc[v].ci = -2;
+            sfa[v] = sfb[v] = 0.0;
+            ya_lo[v] = ya_hi[v] = yb_lo[v] = yb_hi[v] = 0.0;
+            double pshv = 0.0;
+            if (THERMO) {
+                pshv = psh.get(c2 + v);
+                sfa[v] = dsfc.a.get(c2 + v);
+                sfb[v] = dsfc.b.get(c2 + v);
+                bool bad = false;
+                if (pshv > pt.pmax) sc[v].ksfc = S - 1;                        // functions.py:356-359
+                else if (pshv < pt.pmin) bad = true;                          // :360-361
+                else {                                                        // :362-365
+                    for (int i = 0; i < S; ++i) if (pshv > s_p[i]) sc[v].ksfc = i;
+                    if (sc[v].ksfc < 0) bad = true;
+                    sc[v].fill = true;
+                }
+                if (bad) { report(st, 15, c2 + v); sc[v].ksfc = -1; sc[v].fill = false; }
+                sc[v].lnps = pgw_log(pshv);
+            }
+            if (check_top) {                                                  // np.min(source_P), :417
+                for (int i = 0; i < S; ++i) {
+                    double p = (THERMO && i == sc[v].ksfc) ? pshv : s_p[i];
+                    if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
+                }
+            }
+        }
+        auto srcx = [&](int v, int i) -> double { return (THERMO && i == sc[v].ksfc) ? sc[v].lnps : s_lnp[i]; };
+        auto is_sfc = [&](int v, int i) -> bool {
+            return THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (sc[v].fill && i > sc[v].ksfc));
+        };
+        // make source levels i, i+1 (clamped) of column v current in the caches
+        auto ensure = [&](int v, int i) {
+            if (sc[v].ci == i) return;
+            int i2 = (i + 1 < S) ? i + 1 : i;
+            long long o1 = dbase + v + (long long)(S - 1 - i) * ncol;
+            long long o2 = dbase + v + (long long)(S - 1 - i2) * ncol;
+            ya_lo[v] = is_sfc(v, i) ? sfa[v] : d3.a.get(o1);
+            yb_lo[v] = is_sfc(v, i) ? sfb[v] : d3.b.get(o1);
+            ya_hi[v] = is_sfc(v, i2) ? sfa[v] : d3.a.get(o2);
+            yb_hi[v] = is_sfc(v, i2) ? sfb[v] : d3.b.get(o2);
+            sc[v].ci = i;
+        };
+        // software pipeline: level l+1 is in flight while level l is processed
+        double na[V], nb[V];
+        loadv<T, V>(fa + base, na);
+        loadv<T, V>(fb + base, nb);
+        for (int l = 0; l < N; ++l) {
+            double ca[V], cb[V], ra[V], rb[V], rh[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { ca[v] = na[v]; cb[v] = nb[v]; }
+            if (l + 1 < N) {
+                loadv<T, V>(fa + base + (long long)(l + 1) * ncol, na);
+                loadv<T, V>(fb + base + (long long)(l + 1) * ncol, nb);
+            }
+            double am = lv.akm[l], bm = lv.bkm[l];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                double pa = am + ps[v] * bm;                                   // step_03:87-88
+                if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
+                double x = pgw_log(pa);                                           // functions.py:471
+                ColScan &c = sc[v];
+                if (!(x >= c.xprev)) c.j = 0;
+                while (c.j < S) {
+                    double xs = srcx(v, c.j);
+                    if (xs == x || xs > x) break;
+                    ++c.j;
+                }
+                c.xprev = (x == x) ? x : __builtin_inf();
+                double da, db;
+                if (c.j >= S) {                               // above range, constant      :558-560
+                    ensure(v, S - 1); da = ya_lo[v]; db = yb_lo[v];
+                } else {
+                    double xs = srcx(v, c.j);
+                    if (xs == x) {                            // exact                      :540-543
+                        if (c.ci == c.j - 1 && c.j > 0) { da = ya_hi[v]; db = yb_hi[v]; }
+                        else { ensure(v, c.j); da = ya_lo[v]; db = yb_lo[v]; }
+                    } else if (c.j == 0) {                    // below range, constant      :534-536
+                        ensure(v, 0); da = ya_lo[v]; db = yb_lo[v];
+                    } else {                                  // bracket                    :545-548,575-578
+                        ensure(v, c.j - 1);
+                        double x1 = srcx(v, c.j - 1);
+                        double dx = x - x1, Dx = xs - x1;
+                        da = ya_lo[v] + dx * (ya_hi[v] - ya_lo[v]) / Dx;
+                        db = yb_lo[v] + dx * (yb_hi[v] - yb_lo[v]) / Dx;
+                    }
+                }
+                if (THERMO) {
+                    double rh_era = q_to_rh(cb[v], pa, ca[v]);                 // step_03:91-94
+                    double ta_pgw = ca[v] + da;                                // step_03:170-173
+                    double hur_pgw = rh_era + db;
+                    ra[v] = ta_pgw;
+                    rb[v] = rh_to_e(hur_pgw, ta_pgw);                          // functions.py:123
+                    rh[v] = hur_pgw;
+                } else {
+                    ra[v] = ca[v] + da;
+                    rb[v] = cb[v] + db;
+                }
+            }
+            storev<T, V>(out_a + base + (long long)l * ncol, ra);
+            storev<T, V>(out_b + base + (long long)l * ncol, rb);
+            if (THERMO && out_hur) storev<T, V>(out_hur + base + (long long)l * ncol, rh);
+        }
+    }
+    if (check_top) {
+        double wt = wave_min(min_t), ws = wave_min(min_s);
+        int wn = nanflag;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wn |= __shfl_xor(wn, off, 64);
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_mint[w] = wt; s_mins[w] = ws; s_nan[w] = wn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mt = s_mint[0], ms = s_mins[0];
+            int nn = s_nan[0];
+            for (int i = 1; i < BLOCK / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
             if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
             if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
             if (nn) atomicOr(&st->nan_seen, nn);
@@ -717,6 +966,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_update(int ntime, long long n
     double comb = ts;                                                 // functions.py:1180-1181
     if (ice0 == ice0 && tos == tos) {                                 // :1173
         double fr = fmin(fmax(ice0 + lf, 0.0), 1.0);                  // :1183
+        if (lf != lf) fr = __builtin_nan("");                         // np.clip keeps NaN
         comb = fr * ts + (1 - fr) * tos;                              // :1184
     }
     if (comb_out) comb_out[i] = (T)comb;
@@ -786,11 +1036,66 @@ __global__ __launch_bounds__(BLOCK) void k_integrate_tos(long long n, const T *_
     out[i] = (T)r;
 }
 
+// g * time-interpolated zg delta at p_ref -> fp64 loop constant (step_03:292-295)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z, double g, double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = z.get(i) * g;
+}
+
+// surface riders with the time lerp of the three 2-D deltas fused in (step_03:103-146)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long long ncol, SoilTable soil,
+                                                               const T *__restrict__ sic, DeltaSrc<T> dsic, DeltaSrc<T> dtos,
+                                                               DeltaSrc<T> dts, const T *__restrict__ land,
+                                                               const T *__restrict__ clim, const T *__restrict__ tskin,
+                                                               const T *__restrict__ tso, T *__restrict__ sic_out,
+                                                               T *__restrict__ tskin_out, T *__restrict__ tso_out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long n = (long long)ntime * ncol;
+    if (i >= n) return;
+    long long t = i / ncol, c = i - t * ncol;
+    auto ice_of = [&](long long k) -> double {
+        double s0 = (double)sic[k], d0 = dsic.get(k);
+        double v = s0 + d0 / 100;                                     // step_03:105
+        v = fmin(fmax(v, 0.0), 1.0);                                  // :106-107
+        if (s0 != s0 || d0 != d0) v = __builtin_nan("");              // np.clip keeps NaN
+        return v;
+    };
+    double ice = ice_of(i);
+    sic_out[i] = (T)ice;
+    double ice0 = (t == 0) ? ice : ice_of(c);                         // .isel(time=0), :121-122
+    double tos = dtos.get(i), ts = dts.get(i);
+    double comb = ts;                                                 // functions.py:1180-1181
+    if (ice0 == ice0 && tos == tos) {                                 // :1173
+        double fr = fmin(fmax(ice0 + (double)land[c], 0.0), 1.0);     // :1183
+        if ((double)land[c] != (double)land[c]) fr = __builtin_nan("");
+        comb = fr * ts + (1 - fr) * tos;                              // :1184
+    }
+    tskin_out[i] = (T)((double)tskin[i] + comb);                      // step_03:124
+    if (tso_out) {
+        double cl = (double)clim[c];                                  // :134-136
+#pragma unroll
+        for (int s = 0; s < MAX_SOIL; ++s) {
+            if (s < soil.n) {
+                long long o = (t * soil.n + s) * ncol + c;
+                tso_out[o] = (T)((double)tso[o] + (cl + soil.w[s] * (comb - cl)));   // :139-144
+            }
+        }
+    }
+}
+
+// pgw_log over an array (diagnostic entry pgw_test_log; tests compare it with numpy's log)
+__global__ void k_test_log(long long n, const double *__restrict__ in, double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pgw_log(in[i]);
+}
+
 // ln() of a small table with the device log (so table entries and per-column logs come from
 // the same implementation)
 __global__ void k_log_table(int n, const double *in, double *out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = log(in[i]);
+    if (i < n) out[i] = pgw_log(in[i]);
 }
 
 }  // namespace pgw

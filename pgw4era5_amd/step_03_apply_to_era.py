@@ -132,9 +132,9 @@ def _upload_era(ctx, era, dtype):
 
 
 def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, out=None, want=('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE')):
+                        p_ref=None, out=None, keep_hur=False):
     """The per-file compute path of pgw_for_era5 (reference step_03:62-346, i_reinterp = 0,
-    fixed p_ref) on device arrays.
+    fixed p_ref) on device arrays: ONE call into the C-ABI (`pgw_step03_file`).
 
     era: dict of DeviceArrays PS,FIS,(T_SKIN,FR_LAND,FR_SEA_ICE) (1,nlat,nlon); T,QV,U,V
     (1,N,nlat,nlon); T_SO (1,nsoil,nlat,nlon).  coeffs: dict ak,bk,[akm,bkm],soil1 (host).
@@ -143,11 +143,9 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     lib, h = ctx.lib, ctx.handle
     p_ref = S.p_ref_inp if p_ref is None else p_ref
     dt = deltas.dtype
-    tag = dtype_tag(dt)
     ctx.set_levels(coeffs['ak'], coeffs['bk'], coeffs.get('akm'), coeffs.get('bkm'))
-    T, QV, PS = era['T'], era['QV'], era['PS']
+    T, PS = era['T'], era['PS']
     nt, N, nlat, nlon = T.shape
-    ncol = nlat * nlon
     out = {} if out is None else out
 
     def buf(name, shape):
@@ -155,68 +153,52 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
             out[name] = ctx.empty(shape, dt)
         return out[name]
 
-    # relative humidity of the ERA state (step_03:91-94), pa = akm + PS*bkm in registers
-    relhum = buf('_RELHUM', T.shape)
-    ctx._check(lib.pgw_specific_to_relative_humidity_hybrid(h, tag, nt, ncol, QV.ptr, PS.ptr, T.ptr, relhum.ptr))
-
-    # surface riders (step_03:103-146)
-    if 'FR_SEA_ICE' in era and 'siconc' in deltas.dev:
-        s3 = era['T_SKIN'].shape
-        dsic = deltas.lerp2d('siconc', target_dt, buf('_dsic', s3))
-        dts = deltas.lerp2d('ts', target_dt, buf('_dts', s3))
-        dtos = deltas.lerp2d('tos', target_dt, buf('_dtos', s3))
-        soil = np.ascontiguousarray(coeffs['soil1'], dtype=np.float64)
-        nsoil = len(soil)
-        ctx._check(lib.pgw_surface_update(
-            h, tag, nt, ncol, nsoil, soil.ctypes.data_as(_dp),
-            era['FR_SEA_ICE'].ptr, dsic.ptr, dtos.ptr, dts.ptr, era['FR_LAND'].ptr, deltas.ts_clim.ptr,
-            era['T_SKIN'].ptr, era['T_SO'].ptr,
-            buf('FR_SEA_ICE', era['FR_SEA_ICE'].shape).ptr, buf('_dts_comb', era['T_SKIN'].shape).ptr,
-            buf('T_SKIN', era['T_SKIN'].shape).ptr, buf('T_SO', era['T_SO'].shape).ptr))
-
-    # 3-D deltas onto model levels + add (step_03:155-173)
-    ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)
+    ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)           # functions.py:224-283
     rb, ra = int(keep[ib]), int(keep[ia])
     plev = deltas.plev
-    nplev = len(plev)
-    era_field = dict(ta=T, hur=relhum, ua=era['U'], va=era['V'])
-    out_name = dict(ta='T', hur='_hur_pgw', ua='U', va='V')
-    for var in ('ta', 'hur', 'ua', 'va'):
-        d = deltas.dev[var]
-        db, da = d.slab(rb), d.slab(ra)
-        if var in ('ta', 'hur'):                                   # functions.py:325-332
-            sfc = deltas.dev[var + 's']
-            psh = deltas.dev['ps_hist']
-            sb, sa, pb, pa_ = sfc.slab(rb).ptr, sfc.slab(ra).ptr, psh.slab(rb).ptr, psh.slab(ra).ptr
-        else:
-            sb = sa = pb = pa_ = None
-        o = buf(out_name[var], T.shape)
-        ctx._check(lib.pgw_vert_interp_delta(
-            h, tag, nt, nplev, N, ncol, plev.ctypes.data_as(_dp), db.ptr, da.ptr, x_hi, x_new,
-            sb, sa, pb, pa_, None, PS.ptr, 1 if ignore_top_pressure_error else 0,
-            era_field[var].ptr, o.ptr))
-
-    # zg delta at p_ref (step_03:292-295: .sel(plev=p_ref), exact label match)
-    kref = np.nonzero(plev == p_ref)[0]
+    kref = np.nonzero(plev == p_ref)[0]                             # .sel(plev=p_ref), step_03:294
     if len(kref) != 1:
         raise KeyError(p_ref)
-    zg = deltas.dev['zg']
-    zb, za = zg.slab(rb).slab(int(kref[0])), zg.slab(ra).slab(int(kref[0]))
-    dzg = buf('_dzg', PS.shape)
-    if x_hi == 0.0:
-        ctx._check(lib.pgw_memcpy_d2d(h, dzg.ptr, zb.ptr, zb.nbytes))
-    else:
-        ctx._check(lib.pgw_time_lerp(h, tag, zb.size, zb.ptr, za.ptr, x_hi, x_new, dzg.ptr))
-
-    # fixed-point loop (step_03:182-319)
-    n_iter = C.c_int(0)
-    hist = (C.c_double * int(S.max_n_iter))()
-    ctx._check(lib.pgw_adjust_ps_loop(
-        h, tag, nt, ncol, PS.ptr, era['FIS'].ptr, T.ptr, QV.ptr, out['T'].ptr, out['_hur_pgw'].ptr, dzg.ptr,
-        float(p_ref), float(S.adj_factor), float(S.thresh_phi_ref_max_error), int(S.max_n_iter),
-        buf('PS', PS.shape).ptr, buf('QV', T.shape).ptr, C.byref(n_iter), hist))
-    info = dict(n_iter=n_iter.value, max_err=[hist[i] for i in range(n_iter.value)],
-                levels_touched=int(lib.pgw_last_levels_touched(h)))
+    a = _lib.FileArgs()
+    a.dtype, a.ntime, a.nlev, a.nplev, a.ncol = dtype_tag(dt), nt, N, len(plev), nlat * nlon
+    a.ignore_top = 1 if ignore_top_pressure_error else 0
+    a.max_n_iter = int(S.max_n_iter)
+    a.p_ref, a.adj_factor, a.thresh = float(p_ref), float(S.adj_factor), float(S.thresh_phi_ref_max_error)
+    a.x_hi, a.x_new = x_hi, x_new
+    for k in ('PS', 'FIS', 'T', 'QV', 'U', 'V'):
+        setattr(a, k, era[k].ptr)
+    a.plev = plev.ctypes.data_as(_dp)
+    dev = deltas.dev
+    for var in ('ta', 'hur', 'ua', 'va'):
+        setattr(a, var + '_b', dev[var].slab(rb).ptr)
+        setattr(a, var + '_a', dev[var].slab(ra).ptr)
+    a.zg_b = dev['zg'].slab(rb).slab(int(kref[0])).ptr
+    a.zg_a = dev['zg'].slab(ra).slab(int(kref[0])).ptr
+    for var, name in (('tas', 'tas'), ('hurs', 'hurs'), ('ps_hist', 'pshist')):
+        setattr(a, name + '_b', dev[var].slab(rb).ptr)
+        setattr(a, name + '_a', dev[var].slab(ra).ptr)
+    soil = None
+    if 'FR_SEA_ICE' in era and 'siconc' in dev:                     # surface riders, step_03:103-146
+        soil = np.ascontiguousarray(coeffs['soil1'], dtype=np.float64)
+        a.nsoil = len(soil)
+        a.soil_depth = soil.ctypes.data_as(_dp)
+        for k in ('T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE'):
+            setattr(a, k, era[k].ptr)
+        for var in ('siconc', 'ts', 'tos'):
+            setattr(a, var + '_b', dev[var].slab(rb).ptr)
+            setattr(a, var + '_a', dev[var].slab(ra).ptr)
+        a.ts_clim = deltas.ts_clim.ptr
+        a.T_SKIN_out = buf('T_SKIN', era['T_SKIN'].shape).ptr
+        a.T_SO_out = buf('T_SO', era['T_SO'].shape).ptr
+        a.FR_SEA_ICE_out = buf('FR_SEA_ICE', era['FR_SEA_ICE'].shape).ptr
+    a.PS_out = buf('PS', PS.shape).ptr
+    for k in ('T', 'QV', 'U', 'V'):
+        setattr(a, k + '_out', buf(k, T.shape).ptr)
+    if keep_hur:
+        a.hur_pgw_out = buf('_hur_pgw', T.shape).ptr
+    ctx._check(lib.pgw_step03_file(h, C.byref(a)))
+    info = dict(n_iter=a.n_iter, max_err=[a.max_err_hist[i] for i in range(min(a.n_iter, 32))],
+                levels_touched=int(a.levels_touched))
     return out, info
 
 
@@ -230,7 +212,7 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     ds = DeltaSet(ctx, deltas, delta_times, plev, dtype)
     e = _upload_era(ctx, era, dtype)
     coeffs = dict(ak=era['ak'], bk=era['bk'], akm=era.get('akm'), bkm=era.get('bkm'), soil1=era['soil1'])
-    out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref)
+    out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref, keep_hur=True)
     res = {k: v.numpy() for k, v in out.items() if not k.startswith('_')}
     res['RELHUM_pgw'] = out['_hur_pgw'].numpy()
     res.update(info)

@@ -304,3 +304,34 @@ def test_regrid_vs_oracle(F):
     want = O.regrid_lat_lon(g['field'], g['src_lat'], g['src_lon'], g['targ_lat'], tl)
     got = F.regrid_field(g['field'], g['src_lat'], g['src_lon'], g['targ_lat'], tl)
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
+def test_device_log_accuracy():
+    """pgw_log (the logarithm every kernel uses) against numpy: <= 1 ulp on positive normal
+    numbers, IEEE special cases through the ocml fallback."""
+    import ctypes as C
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        rng.uniform(1e-4, 1.1e5, 200000),                       # pressures of the path
+        np.exp(rng.uniform(-700, 700, 100000)),                 # all magnitudes
+        1.0 + rng.uniform(-1e-3, 1e-3, 50000),                  # near 1 (cancellation-prone)
+        np.array([1.0, 2.0, 0.5, np.sqrt(0.5), np.nextafter(np.sqrt(0.5), 0), 1e-4, 30000.0, 101325.0,
+                  2.2250738585072014e-308, 1.7976931348623157e308]),
+    ])
+    d_in = ctx.to_device(x, np.float64)
+    d_out = ctx.empty(x.shape, np.float64)
+    ctx._check(ctx.lib.pgw_test_log(ctx.handle, x.size, d_in.ptr, d_out.ptr))
+    got, want = d_out.numpy(), np.log(x)
+    ulp = np.abs(got - want) / np.spacing(np.abs(want) + 1e-300)
+    assert ulp.max() <= 1.0, ulp.max()
+    assert (ulp > 0).mean() < 0.3                               # most values are bit-identical to numpy
+    sp = np.array([0.0, -1.0, np.inf, np.nan, 5e-324, 1e-310])
+    d_in = ctx.to_device(sp, np.float64); d_out = ctx.empty(sp.shape, np.float64)
+    ctx._check(ctx.lib.pgw_test_log(ctx.handle, sp.size, d_in.ptr, d_out.ptr))
+    got = d_out.numpy()
+    with np.errstate(all='ignore'):
+        want = np.log(sp)
+    assert got[0] == -np.inf and np.isnan(got[1]) and got[2] == np.inf and np.isnan(got[3])
+    np.testing.assert_allclose(got[4:], want[4:], rtol=1e-15)
