@@ -325,7 +325,7 @@ extern "C" int pgw_timer_stop(pgw_ctx *ctx, double *ms) {
 // ------------------------------------------------------------------ vertical grid
 extern "C" int pgw_set_levels(pgw_ctx *ctx, int nlev, const double *ak, const double *bk,
                               const double *akm, const double *bkm) {
-    NEED(ctx, nlev >= 1 && nlev <= 100000 && ak && bk, "bad level table");
+    NEED(ctx, nlev >= 1 && nlev <= MAX_NLEV && ak && bk, "nlev must be in [1, 256]");
     NEED(ctx, (akm == nullptr) == (bkm == nullptr), "akm and bkm must both be given or both be NULL");
     std::vector<double> h((size_t)4 * nlev + 2);
     double *pak = h.data(), *pbk = pak + nlev + 1, *pakm = pbk + nlev + 1, *pbkm = pakm + nlev;
@@ -665,6 +665,9 @@ extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int npl
 }
 
 // ------------------------------------------------------------------ ps fixed-point loop
+#ifndef PAIR_U
+#define PAIR_U 4
+#endif
 #ifndef STEP_U
 #define STEP_U 4
 #endif
@@ -883,24 +886,38 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     }
 
     // ---- ta + hur -> T_pgw, e_pgw   and   ua + va -> U_pgw, V_pgw
+    // One column per thread: the pair kernels are bound by fp64 VALU work and LDS capacity
+    // (2*S*8 B of staged source values per column), not by load width.
     {
-        // the pair kernels are fp64-VALU bound, not HBM bound: one column per thread keeps the VGPR count at
-        // 131 (3 waves/SIMD) and measured 20-25 % faster than 16 B per lane (169 VGPRs, 2 waves/SIMD)
-        int vec = pair_vec_env() ? pick_vec(dtype, ncol, {a->T, a->QV, a->U, a->V, a->PS, a->T_out, a->U_out, a->V_out, evap,
-                                                           a->hur_pgw_out, a->ta_b, a->hur_b, a->ua_b, a->va_b})
-                                 : 1;
+        const int S = a->nplev;
+        const size_t per_col = (size_t)2 * S * sizeof(double);
+        const size_t tab = (size_t)2 * N * sizeof(double);            // akm | bkm
+        // LDS capacity bounds the occupancy (304 B of staged source values per column at S = 19):
+        // one-wave blocks pack the 160 KiB best (7 waves per CU at S = 19, N = 137)
+        const int tpb = (per_col * 128 + tab <= 20 * 1024) ? 128 : 64;
+        const size_t lds = per_col * tpb + tab;
+        if (lds > 150 * 1024) return fail(ctx, PGW_ERR_ARG, "pgw_step03_file: too many delta levels (%d)", S);
+        const unsigned int grid = nblocks((long long)ntime * ncol, tpb);
+#define LAUNCH_PAIR(THERMO, TPB, FA, FB, D3, DS, PH, OA, OB, OH)                                                      \
+    do {                                                                                                               \
+        if (lds > 64 * 1024)                                                                                           \
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_delta_pair<T, 1, THERMO, PAIR_U, TPB>,                     \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, PAIR_U, TPB>), dim3(grid), dim3(TPB), lds, ctx->stream,         \
+                           ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
+                           ctx->d_status);                                                                             \
+    } while (0)
         if ((rc = status_reset(ctx))) return rc;
         {
             Prof pr(ctx, PGW_K_THERMO_DELTA);
-            DISPATCH_TV(dtype, vec, {
+            DISPATCH_T(dtype, {
                 PairSrc<T> d3{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
                               {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
                 PairSrc<T> ds{{(const T *)a->tas_b, exact ? nullptr : (const T *)a->tas_a, a->x_hi, a->x_new},
                               {(const T *)a->hurs_b, exact ? nullptr : (const T *)a->hurs_a, a->x_hi, a->x_new}};
                 DeltaSrc<T> ph{(const T *)a->pshist_b, exact ? nullptr : (const T *)a->pshist_a, a->x_hi, a->x_new};
-                hipLaunchKernelGGL((k_delta_pair<T, V, true>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)), dim3(BLOCK), 0,
-                                   ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV, (const T *)a->PS,
-                                   d3, ds, ph, check_top, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, ctx->d_status);
+                if (tpb == 128) LAUNCH_PAIR(true, 128, (const T *)a->T, (const T *)a->QV, d3, ds, ph, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out);
+                else LAUNCH_PAIR(true, 64, (const T *)a->T, (const T *)a->QV, d3, ds, ph, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out);
             });
         }
         HIPCHK(ctx, hipGetLastError());
@@ -909,16 +926,16 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         if ((rc = status_reset(ctx))) return rc;
         {
             Prof pr(ctx, PGW_K_WIND_DELTA);
-            DISPATCH_TV(dtype, vec, {
+            DISPATCH_T(dtype, {
                 PairSrc<T> d3{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
                               {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
                 PairSrc<T> ds{{nullptr, nullptr, 0.0, 0.0}, {nullptr, nullptr, 0.0, 0.0}};
                 DeltaSrc<T> ph{nullptr, nullptr, 0.0, 0.0};
-                hipLaunchKernelGGL((k_delta_pair<T, V, false>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)), dim3(BLOCK), 0,
-                                   ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->U, (const T *)a->V, (const T *)a->PS,
-                                   d3, ds, ph, check_top, (T *)a->U_out, (T *)a->V_out, (T *)nullptr, ctx->d_status);
+                if (tpb == 128) LAUNCH_PAIR(false, 128, (const T *)a->U, (const T *)a->V, d3, ds, ph, (T *)a->U_out, (T *)a->V_out, (T *)nullptr);
+                else LAUNCH_PAIR(false, 64, (const T *)a->U, (const T *)a->V, d3, ds, ph, (T *)a->U_out, (T *)a->V_out, (T *)nullptr);
             });
         }
+#undef LAUNCH_PAIR
         HIPCHK(ctx, hipGetLastError());
         if (check_top) {
             if ((rc = status_check(ctx))) return rc;

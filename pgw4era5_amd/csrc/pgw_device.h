@@ -59,8 +59,16 @@ __device__ __forceinline__ void report(DevStatus *st, int code, long long col) {
 // (0, negative, denormal, inf, NaN) goes to the ocml log.  One implementation serves table
 // entries and per-column values, so `src_x == targ_x` comparisons (functions.py:540) are
 // consistent.
+// keeps a rarely taken block a real (wave-uniform) branch: volatile asm cannot be speculated, so
+// the compiler does not if-convert the block into "compute both sides and select"
+__device__ __forceinline__ double no_speculate(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ double pgw_log(double x) {
-    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);
+    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0))
+        return log(no_speculate(x));
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                  Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
@@ -96,18 +104,27 @@ __device__ __forceinline__ double esat_ice(double ta) {     // :74-89 ice (a4 = 
 // alpha*e_w + (1-alpha)*e_i is evaluated in full only in the mixed range; for alpha in {0,1}
 // the dropped term is exactly 0*finite = 0 for every finite T (e_w, e_i are finite for all
 // T > 32.19 K), so the value is unchanged.
+// Each exp sits behind a real branch (no_speculate): the regimes are wave-uniform over most of
+// the atmosphere, so a wave pays for one exp + one division outside the mixed range.
 __device__ __forceinline__ double esat_mixed(double ta) {
     const double T0 = 273.16, Ti = 250.16;
-    if (ta >= T0) return esat_water(ta);
-    if (ta <= Ti) {
-        if (ta > 40.0) return esat_ice(ta);
-        // unphysical cold: keep the literal expression (0*e_w may be NaN/inf there)
-        return 0.0 * esat_water(ta) + 1.0 * esat_ice(ta);
+    double ew = 0.0, ei = 0.0;
+    const bool cold = (ta <= Ti), warm = (ta >= T0);
+    if (!cold || !(ta > 40.0)) {                                // water term needed (also NaN / unphysical cold)
+        ew = esat_water(no_speculate(ta));
+    }
+    if (!warm) {                                                // ice term needed (also NaN)
+        ei = esat_ice(no_speculate(ta));
+    }
+    if (warm) return ew;
+    if (cold) {
+        if (ta > 40.0) return ei;
+        return 0.0 * ew + 1.0 * ei;                             // unphysical cold: literal expression (0*e_w may be NaN/inf)
     }
     if (ta < T0 && ta > Ti) {
         double r = (ta - Ti) / (T0 - Ti);
         double alpha = r * r;                                   // np.power(x, 2.) == x*x
-        return alpha * esat_water(ta) + (1 - alpha) * esat_ice(ta);
+        return alpha * ew + (1 - alpha) * ei;
     }
     return __builtin_nan("");                                   // NaN temperature
 }

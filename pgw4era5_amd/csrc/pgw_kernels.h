@@ -17,6 +17,30 @@ struct Levels {
     double ps_mono_min;  // columns with ps >= this have strictly ascending half-level pressure
 };
 
+// The tables are staged in LDS by every kernel that walks levels: a coefficient read through the
+// kernel-argument pointer compiles to a VECTOR global load (the compiler cannot prove the table is
+// not aliased by the kernel's stores), and its `s_waitcnt vmcnt` then also waits for every
+// prefetched row and earlier store of the wave (vmcnt retires in order) - one such load per level
+// serialises the whole software pipeline.  ds_read uses lgkmcnt and leaves vmcnt traffic in flight.
+constexpr int MAX_NLEV = 256;
+struct LevTab {            // LDS image: ak[0..N] | bk[0..N] | akm[0..N-1] | bkm[0..N-1]
+    const double *ak, *bk, *akm, *bkm;
+};
+template <bool HALF, bool FULL>
+__device__ __forceinline__ LevTab stage_levels(const Levels &lv, double *lds, int nthreads) {
+    const int N = lv.nlev;
+    LevTab t;
+    t.ak = lds; t.bk = lds + (MAX_NLEV + 1); t.akm = lds + 2 * (MAX_NLEV + 1); t.bkm = t.akm + MAX_NLEV;
+    double *w = lds;
+    for (int i = threadIdx.x; i <= N; i += nthreads) {
+        if (HALF) { w[i] = lv.ak[i]; w[(MAX_NLEV + 1) + i] = lv.bk[i]; }
+        if (FULL && i < N) { w[2 * (MAX_NLEV + 1) + i] = lv.akm[i]; w[2 * (MAX_NLEV + 1) + MAX_NLEV + i] = lv.bkm[i]; }
+    }
+    __syncthreads();
+    return t;
+}
+constexpr int LEVTAB_DOUBLES = 2 * (MAX_NLEV + 1) + 2 * MAX_NLEV;
+
 // flat column group -> (time, column) and base offsets
 struct ColIdx {
     long long t, c;
@@ -37,6 +61,8 @@ template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_pressure_levels(Levels lv, int ntime, long long ncol,
                                                            const T *__restrict__ ps,
                                                            T *__restrict__ pa_hl, T *__restrict__ pa) {
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<true, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     if (g >= ngroups) return;
@@ -48,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void k_pressure_levels(Levels lv, int ntime,
         T *o = pa_hl + ix.t * (N + 1) * ncol + ix.c;
 #pragma unroll 4
         for (int k = 0; k <= N; ++k) {
-            double a = lv.ak[k], b = lv.bk[k], r[V];
+            double a = lt.ak[k], b = lt.bk[k], r[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) r[v] = a + p[v] * b;
             storev<T, V>(o + (long long)k * ncol, r);
@@ -58,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void k_pressure_levels(Levels lv, int ntime,
         T *o = pa + ix.t * N * ncol + ix.c;
 #pragma unroll 4
         for (int l = 0; l < N; ++l) {
-            double a = lv.akm[l], b = lv.bkm[l], r[V];
+            double a = lt.akm[l], b = lt.bkm[l], r[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) r[v] = a + p[v] * b;
             storev<T, V>(o + (long long)l * ncol, r);
@@ -91,6 +117,8 @@ template <typename T, int V, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_humidity_hybrid(Levels lv, int ntime, long long ncol,
                                                            const T *__restrict__ x, const T *__restrict__ ps,
                                                            const T *__restrict__ ta, T *__restrict__ out) {
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     if (g >= ngroups) return;
@@ -104,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void k_humidity_hybrid(Levels lv, int ntime,
         double a[V], t[V], r[V];
         loadv<T, V>(x + base + (long long)l * ncol, a);
         loadv<T, V>(ta + base + (long long)l * ncol, t);
-        double am = lv.akm[l], bm = lv.bkm[l];
+        double am = lt.akm[l], bm = lt.bkm[l];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             double pa = am + p[v] * bm;
@@ -238,7 +266,7 @@ done:
 // field = QV itself).  Levels are processed in chunks of U with the next chunk's 2*U row loads
 // already in flight (software pipeline; ~2*U KiB per wave outstanding).
 template <typename T, int V, int U, bool SECOND_IS_Q>
-__device__ __forceinline__ void scan_columns(const Levels &lv, long long ncol, const T *__restrict__ pt,
+__device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt, long long ncol, const T *__restrict__ pt,
                                              const T *__restrict__ pe, const double (&ps)[V], const double (&z)[V],
                                              const double (&pref)[V], int full_column, DevStatus *st, long long c2,
                                              double (&phi_ref)[V], double (&tlow)[V], int &touched) {
@@ -246,7 +274,7 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, long long ncol, c
     GeoAcc acc[V];
     bool mono[V];
     {
-        double akN = lv.ak[N], bkN = lv.bk[N];
+        double akN = lt.ak[N], bkN = lt.bk[N];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             geo_init(acc[v], z[v], akN + ps[v] * bkN);          // step_03:198
@@ -280,7 +308,7 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, long long ncol, c
         for (int u = 0; u < U; ++u) {
             int lc = l - u;
             if (lc >= 0) {
-                double am = lv.akm[lc], bm = lv.bkm[lc], a = lv.ak[lc], b = lv.bk[lc];
+                double am = lt.akm[lc], bm = lt.bkm[lc], a = lt.ak[lc], b = lt.bk[lc];
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
                     double q;
@@ -314,6 +342,8 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
                                                           double adj_factor, int full_column, DevStatus *st) {
     __shared__ double s_max[BLOCK / 64];
     __shared__ unsigned int s_valid[BLOCK / 64];
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<true, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     double amax = -1.0;       // max |err| of this thread's valid columns (-1 = none)
@@ -338,7 +368,7 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
             ps[v] = ps0[v] + dps[v];                        // :193
         }
         storev<double, V>(delta_ps + c2, dps);
-        scan_columns<T, V, U, false>(lv, ncol, ta + ix.t * N * ncol + ix.c, evap + ix.t * N * ncol + ix.c, ps, z, pref,
+        scan_columns<T, V, U, false>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, evap + ix.t * N * ncol + ix.c, ps, z, pref,
                                      full_column, st, c2, phi_ref, tlow, touched);
         double nadj[V];
 #pragma unroll
@@ -379,6 +409,8 @@ __global__ __launch_bounds__(BLOCK) void k_phi_ref_hybrid(Levels lv, int ntime, 
                                                           const T *__restrict__ PS, const T *__restrict__ FIS,
                                                           double p_ref_s, const double *__restrict__ p_ref_f,
                                                           double *__restrict__ phi_out, int full_column, DevStatus *st) {
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<true, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     if (g >= ngroups) return;
@@ -394,7 +426,7 @@ __global__ __launch_bounds__(BLOCK) void k_phi_ref_hybrid(Levels lv, int ntime, 
 #pragma unroll
         for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
     }
-    scan_columns<T, V, U, true>(lv, ncol, ta + ix.t * N * ncol + ix.c, hus + ix.t * N * ncol + ix.c, ps, z, pref,
+    scan_columns<T, V, U, true>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, hus + ix.t * N * ncol + ix.c, ps, z, pref,
                                 full_column, st, c2, phi_ref, tlow, touched);
     storev<double, V>(phi_out + c2, phi_ref);
 }
@@ -405,6 +437,8 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
                                                            const T *__restrict__ PS, const double *__restrict__ delta_ps,
                                                            const T *__restrict__ evap, T *__restrict__ ps_out,
                                                            T *__restrict__ hus_out) {
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     if (g >= ngroups) return;
@@ -423,7 +457,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
         for (int l = 0; l < N; ++l) {
             double e[V], r[V];
             loadv<T, V>(evap + base + (long long)l * ncol, e);
-            double am = lv.akm[l], bm = lv.bkm[l];
+            double am = lt.akm[l], bm = lt.bkm[l];
 #pragma unroll
             for (int v = 0; v < V; ++v) r[v] = e_to_q(e[v], am + ps[v] * bm);
             storev<T, V>(hus_out + base + (long long)l * ncol, r);
@@ -573,6 +607,10 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
     __shared__ int s_nan[BLOCK / 64];
     // plev / ln(plev) staged in LDS: lanes index them with their own (divergent) scan position
     __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt;
+    lt.akm = lt.bkm = nullptr;
+    if (!trgP) lt = stage_levels<false, true>(lv, s_lev, BLOCK);
     const int S = pt.n;
     if (threadIdx.x < MAX_PLEV) {
         s_p[threadIdx.x] = pt.p[threadIdx.x];
@@ -626,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
         int ci = -2;                 // cached bracket index: values y[ci], y[ci+1]
         double y_lo = 0.0, y_hi = 0.0;
         for (int l = 0; l < N; ++l) {
-            double p = ptg ? (double)ptg[(long long)l * ncol] : (lv.akm[l] + psv * lv.bkm[l]);
+            double p = ptg ? (double)ptg[(long long)l * ncol] : (lt.akm[l] + psv * lt.bkm[l]);
             if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
             double x = pgw_log(p);
             if (!(x >= xprev)) j = 0;
@@ -689,11 +727,9 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
 // =====================================================================================
 struct ColScan {
     int ksfc;          // source level moved to ps_hist (-1: none)
-    bool fill;         // levels below ksfc take the surface delta too
     double lnps;       // ln(ps_hist)
     int j;             // current "first source index with sx >= x"
     double xprev;
-    int ci;            // cached bracket: values of source levels ci, ci+1
 };
 
 template <typename T>
@@ -701,23 +737,33 @@ struct PairSrc {       // the two variables of a pair
     DeltaSrc<T> a, b;
 };
 
-template <typename T, int V, bool THERMO>
-__global__ __launch_bounds__(BLOCK) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
-                                                      const T *__restrict__ fa, const T *__restrict__ fb,
-                                                      const T *__restrict__ PS,
-                                                      PairSrc<T> d3, PairSrc<T> dsfc, DeltaSrc<T> psh,
-                                                      int check_top, T *__restrict__ out_a, T *__restrict__ out_b,
-                                                      T *__restrict__ out_hur, DevStatus *st) {
-    __shared__ double s_mint[BLOCK / 64], s_mins[BLOCK / 64];
-    __shared__ int s_nan[BLOCK / 64];
-    __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
+// The S source values of both variables of every column (time-lerped, surface delta inserted)
+// are staged ONCE in LDS, laid out [level][thread] (conflict-free for any per-lane level index),
+// so the level loop does no global gathers: a gather's `s_waitcnt vmcnt(0)` would also wait for
+// the prefetched rows and all earlier stores and serialise the whole pipeline.
+template <typename T, int V, bool THERMO, int U, int TPB>
+__global__ __launch_bounds__(TPB) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
+                                                    const T *__restrict__ fa, const T *__restrict__ fb,
+                                                    const T *__restrict__ PS,
+                                                    PairSrc<T> d3, PairSrc<T> dsfc, DeltaSrc<T> psh,
+                                                    int check_top, T *__restrict__ out_a, T *__restrict__ out_b,
+                                                    T *__restrict__ out_hur, DevStatus *st) {
+    extern __shared__ double lds_pair[];            // ya[S][V*TPB] | yb[S][V*TPB] | akm[N] | bkm[N]
+    __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
+    __shared__ int s_nan[TPB / 64];
+    __shared__ double s_lnp[MAX_PLEV];
     const int S = pt.n;
-    if (threadIdx.x < MAX_PLEV) {
-        s_p[threadIdx.x] = pt.p[threadIdx.x];
-        s_lnp[threadIdx.x] = pt.lnp[threadIdx.x];
+    constexpr int W = V * TPB;                      // column slots per block
+    double *s_akm = lds_pair + (size_t)2 * S * W, *s_bkm = s_akm + lv.nlev;
+    for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
+    for (int i = threadIdx.x; i < lv.nlev; i += TPB) {
+        s_akm[i] = lv.akm[i];
+        s_bkm[i] = lv.bkm[i];
     }
     __syncthreads();
-    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double *ya = lds_pair + threadIdx.x;            // slot of column v: + v*TPB ; level i: + i*W
+    double *yb = lds_pair + (size_t)S * W + threadIdx.x;
+    long long g = (long long)blockIdx.x * TPB + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     double min_t = __builtin_inf(), min_s = __builtin_inf();
     int nanflag = 0;
@@ -730,112 +776,116 @@ __global__ __launch_bounds__(BLOCK) void k_delta_pair(PlevTable pt, Levels lv, i
         double ps[V];
         loadv<T, V>(PS + c2, ps);
         ColScan sc[V];
-        double sfa[V], sfb[V];                        // surface deltas of the two variables
-        double ya_lo[V], ya_hi[V], yb_lo[V], yb_hi[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            sc[v].ksfc = -1; sc[v].fill = false; sc[v].lnps = 0.0; sc[v].j = 0;
-            sc[v].xprev = -__builtin_inf(); sc[v].ci = -2;
-            sfa[v] = sfb[v] = 0.0;
-            ya_lo[v] = ya_hi[v] = yb_lo[v] = yb_hi[v] = 0.0;
-            double pshv = 0.0;
+            sc[v].ksfc = -1; sc[v].lnps = 0.0; sc[v].j = 0; sc[v].xprev = -__builtin_inf();
+            bool fill = false;
+            double sfa = 0.0, sfb = 0.0, pshv = 0.0;
             if (THERMO) {
                 pshv = psh.get(c2 + v);
-                sfa[v] = dsfc.a.get(c2 + v);
-                sfb[v] = dsfc.b.get(c2 + v);
+                sfa = dsfc.a.get(c2 + v);
+                sfb = dsfc.b.get(c2 + v);
                 bool bad = false;
                 if (pshv > pt.pmax) sc[v].ksfc = S - 1;                        // functions.py:356-359
                 else if (pshv < pt.pmin) bad = true;                          // :360-361
                 else {                                                        // :362-365
-                    for (int i = 0; i < S; ++i) if (pshv > s_p[i]) sc[v].ksfc = i;
+                    for (int i = 0; i < S; ++i) if (pshv > pt.p[i]) sc[v].ksfc = i;     // uniform index: scalar loads
                     if (sc[v].ksfc < 0) bad = true;
-                    sc[v].fill = true;
+                    fill = true;
                 }
-                if (bad) { report(st, 15, c2 + v); sc[v].ksfc = -1; sc[v].fill = false; }
+                if (bad) { report(st, 15, c2 + v); sc[v].ksfc = -1; fill = false; }
                 sc[v].lnps = pgw_log(pshv);
             }
-            if (check_top) {                                                  // np.min(source_P), :417
-                for (int i = 0; i < S; ++i) {
-                    double p = (THERMO && i == sc[v].ksfc) ? pshv : s_p[i];
+            // stage the source column of both variables (ascending order i <-> file index S-1-i)
+            for (int i = 0; i < S; ++i) {
+                long long o = dbase + v + (long long)(S - 1 - i) * ncol;
+                bool sfc = THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (fill && i > sc[v].ksfc));
+                ya[i * W + v * TPB] = sfc ? sfa : d3.a.get(o);
+                yb[i * W + v * TPB] = sfc ? sfb : d3.b.get(o);
+                if (check_top) {                                              // np.min(source_P), :417
+                    double p = (THERMO && i == sc[v].ksfc) ? pshv : pt.p[i];
                     if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
                 }
             }
         }
         auto srcx = [&](int v, int i) -> double { return (THERMO && i == sc[v].ksfc) ? sc[v].lnps : s_lnp[i]; };
-        auto is_sfc = [&](int v, int i) -> bool {
-            return THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (sc[v].fill && i > sc[v].ksfc));
-        };
-        // make source levels i, i+1 (clamped) of column v current in the caches
-        auto ensure = [&](int v, int i) {
-            if (sc[v].ci == i) return;
-            int i2 = (i + 1 < S) ? i + 1 : i;
-            long long o1 = dbase + v + (long long)(S - 1 - i) * ncol;
-            long long o2 = dbase + v + (long long)(S - 1 - i2) * ncol;
-            ya_lo[v] = is_sfc(v, i) ? sfa[v] : d3.a.get(o1);
-            yb_lo[v] = is_sfc(v, i) ? sfb[v] : d3.b.get(o1);
-            ya_hi[v] = is_sfc(v, i2) ? sfa[v] : d3.a.get(o2);
-            yb_hi[v] = is_sfc(v, i2) ? sfb[v] : d3.b.get(o2);
-            sc[v].ci = i;
-        };
-        // software pipeline: level l+1 is in flight while level l is processed
-        double na[V], nb[V];
-        loadv<T, V>(fa + base, na);
-        loadv<T, V>(fb + base, nb);
-        for (int l = 0; l < N; ++l) {
-            double ca[V], cb[V], ra[V], rb[V], rh[V];
+        // software pipeline: chunks of U levels; the next chunk's 2*U row loads are in flight while
+        // the current chunk is processed
+        double na[U][V], nb[U][V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) { ca[v] = na[v]; cb[v] = nb[v]; }
-            if (l + 1 < N) {
-                loadv<T, V>(fa + base + (long long)(l + 1) * ncol, na);
-                loadv<T, V>(fb + base + (long long)(l + 1) * ncol, nb);
-            }
-            double am = lv.akm[l], bm = lv.bkm[l];
+        for (int u = 0; u < U; ++u) {
+            int lu = u < N ? u : N - 1;
+            loadv<T, V>(fa + base + (long long)lu * ncol, na[u]);
+            loadv<T, V>(fb + base + (long long)lu * ncol, nb[u]);
+        }
+        for (int l0 = 0; l0 < N; l0 += U) {
+            double ca[U][V], cb[U][V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                double pa = am + ps[v] * bm;                                   // step_03:87-88
-                if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
-                double x = pgw_log(pa);                                           // functions.py:471
-                ColScan &c = sc[v];
-                if (!(x >= c.xprev)) c.j = 0;
-                while (c.j < S) {
-                    double xs = srcx(v, c.j);
-                    if (xs == x || xs > x) break;
-                    ++c.j;
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < V; ++v) { ca[u][v] = na[u][v]; cb[u][v] = nb[u][v]; }
+            if (l0 + U < N) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    int lu = (l0 + U + u) < N ? (l0 + U + u) : N - 1;
+                    loadv<T, V>(fa + base + (long long)lu * ncol, na[u]);
+                    loadv<T, V>(fb + base + (long long)lu * ncol, nb[u]);
                 }
-                c.xprev = (x == x) ? x : __builtin_inf();
-                double da, db;
-                if (c.j >= S) {                               // above range, constant      :558-560
-                    ensure(v, S - 1); da = ya_lo[v]; db = yb_lo[v];
-                } else {
-                    double xs = srcx(v, c.j);
-                    if (xs == x) {                            // exact                      :540-543
-                        if (c.ci == c.j - 1 && c.j > 0) { da = ya_hi[v]; db = yb_hi[v]; }
-                        else { ensure(v, c.j); da = ya_lo[v]; db = yb_lo[v]; }
-                    } else if (c.j == 0) {                    // below range, constant      :534-536
-                        ensure(v, 0); da = ya_lo[v]; db = yb_lo[v];
-                    } else {                                  // bracket                    :545-548,575-578
-                        ensure(v, c.j - 1);
-                        double x1 = srcx(v, c.j - 1);
-                        double dx = x - x1, Dx = xs - x1;
-                        da = ya_lo[v] + dx * (ya_hi[v] - ya_lo[v]) / Dx;
-                        db = yb_lo[v] + dx * (yb_hi[v] - yb_lo[v]) / Dx;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int l = l0 + u;
+                if (l < N) {
+                    double ra[V], rb[V], rh[V];
+                    double am = s_akm[l], bm = s_bkm[l];
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        double pa = am + ps[v] * bm;                                   // step_03:87-88
+                        if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
+                        double x = pgw_log(pa);                                       // functions.py:471
+                        ColScan &c = sc[v];
+                        if (!(x >= c.xprev)) c.j = 0;
+                        while (c.j < S) {
+                            double xs = srcx(v, c.j);
+                            if (xs == x || xs > x) break;
+                            ++c.j;
+                        }
+                        c.xprev = (x == x) ? x : __builtin_inf();
+                        // i1 == i2: single value; else bracket (i1, i2 = i1 + 1)
+                        int i1, i2;
+                        if (c.j >= S) { i1 = i2 = S - 1; }                            // above range, constant :558-560
+                        else {
+                            double xs = srcx(v, c.j);
+                            if (xs == x) { i1 = i2 = c.j; }                           // exact                 :540-543
+                            else if (c.j == 0) { i1 = i2 = 0; }                       // below range, constant :534-536
+                            else { i1 = c.j - 1; i2 = c.j; }                          // bracket               :545-548
+                        }
+                        double a1 = ya[i1 * W + v * TPB], b1 = yb[i1 * W + v * TPB];
+                        double da = a1, db = b1;
+                        if (i1 != i2) {                                               // :575-578
+                            double a2 = ya[i2 * W + v * TPB], b2 = yb[i2 * W + v * TPB];
+                            double x1 = srcx(v, i1), x2 = srcx(v, i2);
+                            double dx = x - x1, Dx = x2 - x1;
+                            da = a1 + dx * (a2 - a1) / Dx;
+                            db = b1 + dx * (b2 - b1) / Dx;
+                        }
+                        if (THERMO) {
+                            double rh_era = q_to_rh(cb[u][v], pa, ca[u][v]);           // step_03:91-94
+                            double ta_pgw = ca[u][v] + da;                             // step_03:170-173
+                            double hur_pgw = rh_era + db;
+                            ra[v] = ta_pgw;
+                            rb[v] = rh_to_e(hur_pgw, ta_pgw);                          // functions.py:123
+                            rh[v] = hur_pgw;
+                        } else {
+                            ra[v] = ca[u][v] + da;
+                            rb[v] = cb[u][v] + db;
+                        }
                     }
-                }
-                if (THERMO) {
-                    double rh_era = q_to_rh(cb[v], pa, ca[v]);                 // step_03:91-94
-                    double ta_pgw = ca[v] + da;                                // step_03:170-173
-                    double hur_pgw = rh_era + db;
-                    ra[v] = ta_pgw;
-                    rb[v] = rh_to_e(hur_pgw, ta_pgw);                          // functions.py:123
-                    rh[v] = hur_pgw;
-                } else {
-                    ra[v] = ca[v] + da;
-                    rb[v] = cb[v] + db;
+                    storev<T, V>(out_a + base + (long long)l * ncol, ra);
+                    storev<T, V>(out_b + base + (long long)l * ncol, rb);
+                    if (THERMO && out_hur) storev<T, V>(out_hur + base + (long long)l * ncol, rh);
                 }
             }
-            storev<T, V>(out_a + base + (long long)l * ncol, ra);
-            storev<T, V>(out_b + base + (long long)l * ncol, rb);
-            if (THERMO && out_hur) storev<T, V>(out_hur + base + (long long)l * ncol, rh);
         }
     }
     if (check_top) {
@@ -849,7 +899,7 @@ __global__ __launch_bounds__(BLOCK) void k_delta_pair(PlevTable pt, Levels lv, i
         if (threadIdx.x == 0) {
             double mt = s_mint[0], ms = s_mins[0];
             int nn = s_nan[0];
-            for (int i = 1; i < BLOCK / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
+            for (int i = 1; i < TPB / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
             if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
             if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
             if (nn) atomicOr(&st->nan_seen, nn);
