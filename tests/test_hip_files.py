@@ -112,3 +112,24 @@ def test_step02_cli_regridding(tmp_path):
     assert res['ta'].attrs['units'] == 'K'
     with pytest.raises(NotImplementedError):
         s2.main(['regridding', '-i', str(inp), '-o', str(out), '-e', str(tmp_path / 'era.nc'), '-v', 'tos'])
+
+
+def test_step03_cli_two_worker_ranks(files):
+    """-p 2: two self-spawned worker processes (one per rank; on a 1-GPU box both bind to GPU 0),
+    files dealt round-robin, same outputs as the serial run."""
+    from pgw4era5_amd import step_03_apply_to_era as s3, ncio
+    root, cases = files
+    out_dir = str(root / 'out_p2')
+    n_iters = s3._cli(['-i', str(root / 'era'), '-o', out_dir, '-d', str(root / 'deltas'),
+                       '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '2', '-t'])
+    assert len(n_iters) == 2 and all(isinstance(n, int) for n in n_iters)
+    serial = str(root / 'out')
+    if not os.path.exists(os.path.join(serial, 'cas20060802000000.nc')):
+        s3._cli(['-i', str(root / 'era'), '-o', serial, '-d', str(root / 'deltas'),
+                 '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '1', '-t'])
+    for c in cases:
+        name = 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])
+        a = ncio.open_dataset(os.path.join(out_dir, name), decode_times=False)
+        b = ncio.open_dataset(os.path.join(serial, name), decode_times=False)
+        for v in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+            np.testing.assert_array_equal(a[v].values, b[v].values, err_msg=v)
