@@ -741,20 +741,23 @@ struct PairSrc {       // the two variables of a pair
 // are staged ONCE in LDS, laid out [level][thread] (conflict-free for any per-lane level index),
 // so the level loop does no global gathers: a gather's `s_waitcnt vmcnt(0)` would also wait for
 // the prefetched rows and all earlier stores and serialise the whole pipeline.
-template <typename T, int V, bool THERMO, int U, int TPB>
+template <typename T, int V, bool THERMO, int U, int TPB, bool STAGED>
 __global__ __launch_bounds__(TPB) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                     const T *__restrict__ fa, const T *__restrict__ fb,
                                                     const T *__restrict__ PS,
                                                     PairSrc<T> d3, PairSrc<T> dsfc, DeltaSrc<T> psh,
                                                     int check_top, T *__restrict__ out_a, T *__restrict__ out_b,
                                                     T *__restrict__ out_hur, DevStatus *st) {
-    extern __shared__ double lds_pair[];            // ya[S][V*TPB] | yb[S][V*TPB] | akm[N] | bkm[N]
+    // STAGED:  ya[S][V*TPB] | yb[S][V*TPB] | akm[N] | bkm[N]   (source values in LDS)
+    // !STAGED: akm[N] | bkm[N]; source values are gathered from global memory when a column's
+    //          bracket changes and cached in registers (more waves per CU, a vmcnt(0) stall per change)
+    extern __shared__ double lds_pair[];
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
     __shared__ double s_lnp[MAX_PLEV];
     const int S = pt.n;
     constexpr int W = V * TPB;                      // column slots per block
-    double *s_akm = lds_pair + (size_t)2 * S * W, *s_bkm = s_akm + lv.nlev;
+    double *s_akm = lds_pair + (STAGED ? (size_t)2 * S * W : 0), *s_bkm = s_akm + lv.nlev;
     for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
     for (int i = threadIdx.x; i < lv.nlev; i += TPB) {
         s_akm[i] = lv.akm[i];
@@ -776,9 +779,14 @@ __global__ __launch_bounds__(TPB) void k_delta_pair(PlevTable pt, Levels lv, int
         double ps[V];
         loadv<T, V>(PS + c2, ps);
         ColScan sc[V];
+        bool fillv[V];
+        double sfav[V], sfbv[V];
+        int ci[V];                                    // !STAGED: cached bracket (levels ci, ci+1)
+        double ca_lo[V], ca_hi[V], cb_lo[V], cb_hi[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             sc[v].ksfc = -1; sc[v].lnps = 0.0; sc[v].j = 0; sc[v].xprev = -__builtin_inf();
+            ci[v] = -2; ca_lo[v] = ca_hi[v] = cb_lo[v] = cb_hi[v] = 0.0;
             bool fill = false;
             double sfa = 0.0, sfb = 0.0, pshv = 0.0;
             if (THERMO) {
@@ -796,18 +804,39 @@ __global__ __launch_bounds__(TPB) void k_delta_pair(PlevTable pt, Levels lv, int
                 if (bad) { report(st, 15, c2 + v); sc[v].ksfc = -1; fill = false; }
                 sc[v].lnps = pgw_log(pshv);
             }
+            fillv[v] = fill; sfav[v] = sfa; sfbv[v] = sfb;
             // stage the source column of both variables (ascending order i <-> file index S-1-i)
             for (int i = 0; i < S; ++i) {
-                long long o = dbase + v + (long long)(S - 1 - i) * ncol;
-                bool sfc = THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (fill && i > sc[v].ksfc));
-                ya[i * W + v * TPB] = sfc ? sfa : d3.a.get(o);
-                yb[i * W + v * TPB] = sfc ? sfb : d3.b.get(o);
+                if (STAGED) {
+                    long long o = dbase + v + (long long)(S - 1 - i) * ncol;
+                    bool sfc = THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (fill && i > sc[v].ksfc));
+                    ya[i * W + v * TPB] = sfc ? sfa : d3.a.get(o);
+                    yb[i * W + v * TPB] = sfc ? sfb : d3.b.get(o);
+                }
                 if (check_top) {                                              // np.min(source_P), :417
                     double p = (THERMO && i == sc[v].ksfc) ? pshv : pt.p[i];
                     if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
                 }
             }
         }
+        // !STAGED: values of source levels (i, i+1) of column v, from the register cache or global memory
+        auto fetch = [&](int v, int i1, int i2, double &a1, double &b1, double &a2, double &b2) {
+            auto one = [&](int i, double &a, double &b) {
+                bool sfc = THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (fillv[v] && i > sc[v].ksfc));
+                long long o = dbase + v + (long long)(S - 1 - i) * ncol;
+                a = sfc ? sfav[v] : d3.a.get(o);
+                b = sfc ? sfbv[v] : d3.b.get(o);
+            };
+            if (ci[v] != i1) {
+                if (ci[v] + 1 == i1) { ca_lo[v] = ca_hi[v]; cb_lo[v] = cb_hi[v]; }
+                else one(i1, ca_lo[v], cb_lo[v]);
+                int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+                one(ih, ca_hi[v], cb_hi[v]);
+                ci[v] = i1;
+            }
+            a1 = ca_lo[v]; b1 = cb_lo[v];
+            if (i2 != i1) { a2 = ca_hi[v]; b2 = cb_hi[v]; } else { a2 = a1; b2 = b1; }
+        };
         auto srcx = [&](int v, int i) -> double { return (THERMO && i == sc[v].ksfc) ? sc[v].lnps : s_lnp[i]; };
         // software pipeline: chunks of U levels; the next chunk's 2*U row loads are in flight while
         // the current chunk is processed
@@ -860,10 +889,15 @@ __global__ __launch_bounds__(TPB) void k_delta_pair(PlevTable pt, Levels lv, int
                             else if (c.j == 0) { i1 = i2 = 0; }                       // below range, constant :534-536
                             else { i1 = c.j - 1; i2 = c.j; }                          // bracket               :545-548
                         }
-                        double a1 = ya[i1 * W + v * TPB], b1 = yb[i1 * W + v * TPB];
+                        double a1, b1, a2 = 0.0, b2 = 0.0;
+                        if (STAGED) {
+                            a1 = ya[i1 * W + v * TPB]; b1 = yb[i1 * W + v * TPB];
+                            if (i1 != i2) { a2 = ya[i2 * W + v * TPB]; b2 = yb[i2 * W + v * TPB]; }
+                        } else {
+                            fetch(v, i1, i2, a1, b1, a2, b2);
+                        }
                         double da = a1, db = b1;
                         if (i1 != i2) {                                               // :575-578
-                            double a2 = ya[i2 * W + v * TPB], b2 = yb[i2 * W + v * TPB];
                             double x1 = srcx(v, i1), x2 = srcx(v, i2);
                             double dx = x - x1, Dx = x2 - x1;
                             da = a1 + dx * (a2 - a1) / Dx;
