@@ -45,6 +45,9 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--overlap-streams', type=int, default=2,
                    help='extra (untimed-for-value) region with this many files in flight per GPU on separate HIP streams; 0 = skip')
+    p.add_argument('--extras', action='store_true',
+                   help='also time (outside the timed region) the step_02 regridding of BASELINE.json configs[3] and the '
+                        'PCIe-inclusive per-file rate (pinned host buffers -> H2D -> path -> D2H)')
     p.add_argument('--full-column', action='store_true',
                    help='pass kernel reads every level (input-independent traffic) instead of stopping above p_ref')
     return p.parse_args()
@@ -98,6 +101,8 @@ def main():
     dtype = np.float64 if a.storage == 'f64' else np.float32
     s = np.dtype(dtype).itemsize
     ctx = Context(local)
+    from pgw4era5_amd import device as _device
+    _device._default = ctx                 # the functions.py mirror uses the process-wide context
     t0 = time.time()
     case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1 + rank, dtype=dtype)
     t_gen = time.time() - t0
@@ -177,6 +182,7 @@ def main():
             'roofline': roof,
             'kernels': kern,
             'signature_kernels': micro,
+            'extras': extras(ctx, case, era, coeffs, deltas, a, np) if a.extras else None,
             'overlap': overlap,
             'device': ctx.device_name(),
             'setup_s': round(t_gen, 1),
@@ -235,6 +241,66 @@ def overlap_region(device, era, coeffs, deltas, stamps, a):
         return {'error': errs[0]}
     return {'streams': n, 'files': len(stamps), 'ms_per_file': round(el / len(stamps) * 1e3, 3),
             'files_per_hour_per_gpu': round(len(stamps) / el * 3600.0, 1)}
+
+
+def extras(ctx, case, era, coeffs, deltas, a, np):
+    """Measurements that are reported but are not `value`: (1) step_02 bilinear regridding of one
+    19-level variable x 12 months from a 192x384 Gaussian-like grid to the ERA5 grid
+    (BASELINE.json configs[3]); (2) the PCIe-inclusive rate of the step_03 path: T, QV, U, V, PS
+    from pinned host memory to the device, the path, and T, QV, U, V, PS back."""
+    import ctypes as C
+    from pgw4era5_amd import functions as F, synthetic, step_03_apply_to_era as s3
+    out = {}
+    dt = era['T'].dtype
+    s = dt.itemsize
+    g = synthetic.make_gcm_grid_case(nlat_src=192, nlon_src=384, nlat=a.nlat, nlon=a.nlon, nplev=19, ntime=12, seed=4,
+                                     dtype=dt)
+    src = ctx.to_device(g['field'], dt)
+    F.regrid_field(src, g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon']).free()
+    ctx.profile(True); ctx.profile_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = F.regrid_field(src, g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon'])
+        ctx.sync()
+        r.free()
+    wall = (time.perf_counter() - t0) / reps
+    cnt, ms = ctx.profile_get('regrid')
+    ctx.profile(False); ctx.profile_reset()
+    nbytes = (12 * 19 * a.nlat * a.nlon + g['field'].size) * s
+    out['regrid_one_var_12_months'] = dict(kernel_ms=round(ms / cnt, 3), wall_ms=round(wall * 1e3, 3), algo_GB=round(nbytes / 1e9, 3),
+                                           GBps=round(nbytes / 1e9 / (ms / cnt / 1e3), 1))
+    src.free()
+    # PCIe-inclusive: pinned staging buffers, one stream (copies and kernels serialised; the overlapped
+    # variant is bounded by the same PCIe time, which dominates)
+    names = ('T', 'QV', 'U', 'V')
+    n4 = era['T'].nbytes
+    hp = []
+    for _ in range(4):
+        p = C.c_void_p()
+        ctx._check(ctx.lib.pgw_host_alloc(ctx.handle, n4, C.byref(p)))
+        hp.append(p)
+    for k, p in zip(names, hp):
+        C.memmove(p, case['era'][k].ctypes.data, n4)
+    res = {}
+    s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=res)
+    ctx.sync()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        for k, p in zip(names, hp):
+            ctx._check(ctx.lib.pgw_memcpy_h2d(ctx.handle, era[k].ptr, p, n4))
+        s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=res)
+        for k, p in zip(names, hp):
+            ctx._check(ctx.lib.pgw_memcpy_d2h(ctx.handle, p, res[k].ptr, n4))
+        ctx.sync()
+    el = (time.perf_counter() - t0) / reps
+    for p in hp:
+        ctx.lib.pgw_host_free(ctx.handle, p)
+    out['pcie_inclusive'] = dict(ms_per_file=round(el * 1e3, 2), files_per_hour=round(3600.0 / el, 1),
+                                 GB_moved_each_way=round(4 * n4 / 1e9, 3),
+                                 note='pinned H2D of T,QV,U,V + path + D2H of T,QV,U,V on one stream')
+    return out
 
 
 def microbench(ctx, era, coeffs, a, np, reps=5):

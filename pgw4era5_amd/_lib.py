@@ -17,7 +17,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpgw_hip.so')
+LIB_PATH = os.environ.get('PGW_LIB') or os.path.join(_HERE, 'libpgw_hip.so')   # PGW_LIB: A/B builds only
 
 PGW_F32, PGW_F64 = 0, 1
 EXTRAP = {'off': 0, 'linear': 1, 'constant': 2, 'nan': 3}

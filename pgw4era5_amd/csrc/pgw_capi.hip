@@ -1021,8 +1021,11 @@ extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, in
             if (south_row >= 0 || north_row >= 0)
                 hipLaunchKernelGGL((k_zonal_mean_rows<T>), dim3(nblocks(nfield * 2 * 64, BLOCK)), dim3(BLOCK), 0, ctx->stream, nfield,
                                    nlat_s, nlon_s, (const T *)src, south_row, north_row, dpole);
-            unsigned int gz = (unsigned int)(nfield < 4096 ? nfield : 4096);
-            hipLaunchKernelGGL((k_regrid<T>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+            // z-slices: enough blocks to fill 256 CUs several times over even for small target grids
+            long long xy = (long long)nblocks(nlon_t, BLOCK) * nlat_t;
+            long long want = (8192 + xy - 1) / xy;
+            unsigned int gz = (unsigned int)(want < 1 ? 1 : (want > nfield ? nfield : want));
+            hipLaunchKernelGGL((k_regrid<T, 4>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
                                nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
         });
     }

@@ -981,37 +981,56 @@ struct RegridTables {
     const double *lon_dx, *lon_Dx;
 };
 
-template <typename T>
+// One thread owns one target (lat, lon) point and walks the fields (time x plev planes): the
+// index/weight tables are read once per thread and live in registers, the four source gathers of
+// consecutive lanes fall on ~16 neighbouring source columns (L1/L2 hits; one source plane is
+// 0.6 MB), and each plane's outputs are coalesced row segments.  FCH planes per thread per launch
+// slice (gridDim.z slices) keep >= 8 independent gathers in flight.
+template <typename T, int FU>
 __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, int nlon_s, int nlat_t, int nlon_t,
                                                   const T *__restrict__ src, RegridTables tb,
                                                   const double *__restrict__ pole, T *__restrict__ out) {
     int i = blockIdx.x * BLOCK + threadIdx.x;       // target lon
     int j = blockIdx.y;                             // target lat
     if (i >= nlon_t) return;
-    int jl = tb.lat_lo[j], jh = tb.lat_hi[j];
-    double ldx = tb.lat_dx[j], lDx = tb.lat_Dx[j];
-    int joob = tb.lat_oob[j];
-    int il = tb.lon_lo[i], ih = tb.lon_hi[i];
-    double odx = tb.lon_dx[i], oDx = tb.lon_Dx[i];
-    int ioob = tb.lon_oob[i];
-    for (long long f = blockIdx.z; f < nfield; f += gridDim.z) {
-        const T *s = src + f * (long long)nlat_s * nlon_s;
-        auto val = [&](int row, int col) -> double {
-            if (row < 0) return pole[f * 2 + 0];
-            if (row >= nlat_s) return pole[f * 2 + 1];
-            return (double)s[(long long)row * nlon_s + col];
-        };
-        double r;
-        if (joob || ioob) {
-            r = __builtin_nan("");
-        } else {
-            double a_lo = val(jl, il), a_hi = val(jh, il);
-            double b_lo = val(jl, ih), b_hi = val(jh, ih);
-            double ya = (a_hi - a_lo) / lDx * ldx + a_lo;      // lat pass at the lower lon  :859
-            double yb = (b_hi - b_lo) / lDx * ldx + b_lo;      // lat pass at the upper lon
-            r = (yb - ya) / oDx * odx + ya;                    // lon pass                    :892
+    const int jl = tb.lat_lo[j], jh = tb.lat_hi[j];
+    const double ldx = tb.lat_dx[j], lDx = tb.lat_Dx[j];
+    const int il = tb.lon_lo[i], ih = tb.lon_hi[i];
+    const double odx = tb.lon_dx[i], oDx = tb.lon_Dx[i];
+    const bool oob = tb.lat_oob[j] || tb.lon_oob[i];
+    const long long plane_s = (long long)nlat_s * nlon_s, plane_t = (long long)nlat_t * nlon_t;
+    const bool lo_pole = jl < 0 || jl >= nlat_s, hi_pole = jh < 0 || jh >= nlat_s;
+    const long long o_ll = (long long)(lo_pole ? 0 : jl) * nlon_s + il, o_lh = (long long)(lo_pole ? 0 : jl) * nlon_s + ih;
+    const long long o_hl = (long long)(hi_pole ? 0 : jh) * nlon_s + il, o_hh = (long long)(hi_pole ? 0 : jh) * nlon_s + ih;
+    const int lo_which = jl < 0 ? 0 : 1, hi_which = jh < 0 ? 0 : 1;
+    // fields of this z-slice
+    long long per = (nfield + gridDim.z - 1) / gridDim.z;
+    long long f0 = (long long)blockIdx.z * per, f1 = f0 + per < nfield ? f0 + per : nfield;
+    T *po = out + (long long)j * nlon_t + i;
+    for (long long f = f0; f < f1; f += FU) {
+        double a_lo[FU], a_hi[FU], b_lo[FU], b_hi[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            long long ff = (f + u < f1) ? f + u : f1 - 1;
+            const T *s = src + ff * plane_s;
+            a_lo[u] = lo_pole ? pole[ff * 2 + lo_which] : (double)s[o_ll];
+            b_lo[u] = lo_pole ? pole[ff * 2 + lo_which] : (double)s[o_lh];
+            a_hi[u] = hi_pole ? pole[ff * 2 + hi_which] : (double)s[o_hl];
+            b_hi[u] = hi_pole ? pole[ff * 2 + hi_which] : (double)s[o_hh];
         }
-        out[(f * nlat_t + j) * (long long)nlon_t + i] = (T)r;
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            if (f + u < f1) {
+                double r;
+                if (oob) r = __builtin_nan("");
+                else {
+                    double ya = (a_hi[u] - a_lo[u]) / lDx * ldx + a_lo[u];      // lat pass at the lower lon  :859
+                    double yb = (b_hi[u] - b_lo[u]) / lDx * ldx + b_lo[u];      // lat pass at the upper lon
+                    r = (yb - ya) / oDx * odx + ya;                            // lon pass                    :892
+                }
+                po[(f + u) * plane_t] = (T)r;
+            }
+        }
     }
 }
 
