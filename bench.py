@@ -90,8 +90,16 @@ def main():
         # torch first: libpgw_hip.so then binds to the HIP runtime torch loaded (pgw4era5_amd/_lib.py)
         import torch
         import torch.distributed as dist
+        # 'nccl' IS RCCL on ROCm.  PGW_BENCH_BACKEND=gloo only exists to rehearse the multi-rank code path
+        # on a box with fewer GPUs than ranks (ranks then share devices: local % device_count).
+        backend = os.environ.get('PGW_BENCH_BACKEND', 'nccl')
+        ndev = max(torch.cuda.device_count(), 1)
+        local = local % ndev
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     import numpy as np
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
     from pgw4era5_amd.device import Context
@@ -142,7 +150,8 @@ def main():
     ctx.profile(False)
     if dist is not None:
         import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
