@@ -46,7 +46,8 @@ enum pgw_status {
     PGW_ERR_PS_HIST_ABOVE_TOP = 15,  /* replace_delta_sfc ValueError()               :360-363   */
     PGW_ERR_TOP_PRESSURE = 16,       /* 'ERA5 top pressure is lower than ...'        :417-425   */
     PGW_ERR_NOT_CONVERGED = 17,      /* 'Pressure adjustment did not converge' step_03:313-319  */
-    PGW_ERR_GRID_EXTENT = 18         /* regrid: target exceeds source    functions.py:845-888   */
+    PGW_ERR_GRID_EXTENT = 18,        /* regrid: target exceeds source    functions.py:845-888   */
+    PGW_ERR_NO_P_REF = 19            /* 'No reference pressure level above ...'  step_03:245-251 */
 };
 
 enum pgw_dtype { PGW_F32 = 0, PGW_F64 = 1 };
@@ -227,7 +228,8 @@ unsigned long long pgw_last_levels_touched(pgw_ctx *ctx);
  * Results are identical to calling the function-level entry points in the reference's order. */
 typedef struct pgw_file_args {
     /* shapes */
-    int dtype, ntime, nlev, nplev, nsoil, ignore_top, max_n_iter, _pad0;
+    int dtype, ntime, nlev, nplev, nsoil, ignore_top, max_n_iter;
+    int local_p_ref;      /* != 0: p_ref_inp = None, reference pressure chosen per column and pass (step_03:219-253) */
     long long ncol;
     /* ERA5 file (device) + small host tables */
     const void *PS, *FIS, *T, *QV, *U, *V;                  /* (ntime,ncol) / (ntime,nlev,ncol)   */
@@ -237,6 +239,7 @@ typedef struct pgw_file_args {
     /* delta records (device) */
     const void *ta_b, *ta_a, *hur_b, *hur_a, *ua_b, *ua_a, *va_b, *va_a;   /* (ntime,nplev,ncol) */
     const void *zg_b, *zg_a;                                /* (ntime,ncol): zg delta at plev == p_ref */
+    const void *zg3_b, *zg3_a;                              /* (ntime,nplev,ncol): full zg records (local_p_ref) */
     const void *tas_b, *tas_a, *hurs_b, *hurs_a, *pshist_b, *pshist_a;     /* (ntime,ncol)       */
     const void *siconc_b, *siconc_a, *ts_b, *ts_a, *tos_b, *tos_a, *ts_clim;
     double x_hi, x_new;                                     /* time-lerp abscissae (pgw_time_lerp) */

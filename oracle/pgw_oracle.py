@@ -545,6 +545,57 @@ def adjust_ps_loop(ak, bk, akm, bkm, PS, FIS, T, QV, ta_pgw, hur_pgw, dzg_pref,
                 max_err=hist, phi_ref_era=phi_ref_era, phi_ref_pgw=phi_ref_pgw)
 
 
+def adjust_ps_loop_local_pref(ak, bk, akm, bkm, PS, FIS, T, QV, ta_pgw, hur_pgw, dzg, plev,
+                              adj_factor=ADJ_FACTOR, thresh=THRESH_PHI_REF_MAX_ERROR, max_n_iter=MAX_N_ITER):
+    """The loop with p_ref_inp = None (step_03:219-253): the reference pressure is chosen per
+    column and per pass as the first plev (file order) below 95 % of both surface pressures, never
+    lower in altitude than in the previous pass.  dzg (time, plev, lat, lon) [m] in file order."""
+    PS = np.asarray(PS, dtype=np.float64)
+    plev = np.asarray(plev, dtype=np.float64)
+    level1 = np.arange(1, len(ak) + 1)
+    pa_hl_era, _ = hybrid_pressure(ak, bk, PS, akm, bkm)
+    delta_ps = np.zeros_like(PS)
+    adj_ps = np.zeros_like(PS)
+    phi_ref_max_error = np.inf
+    it = 1
+    hist = []
+    p_ref = None
+    n_lowest = ta_pgw.shape[1] - 1
+    while phi_ref_max_error > thresh:
+        delta_ps = delta_ps + adj_ps
+        ps_pgw = PS + delta_ps
+        pa_hl_pgw, pa_pgw = hybrid_pressure(ak, bk, ps_pgw, akm, bkm)
+        p_min_era = pa_hl_era[:, -1] * 0.95                          # :227-228
+        p_min_pgw = pa_hl_pgw[:, -1] * 0.95                          # :229-230
+        new = np.full(PS.shape, np.nan)
+        idx = np.full(PS.shape, -1, dtype=np.int64)
+        for k in range(len(plev) - 1, -1, -1):                       # first match in file order wins
+            ok = (p_min_era > plev[k]) & (p_min_pgw > plev[k])
+            new = np.where(ok, plev[k], new)
+            idx = np.where(ok, k, idx)
+        if p_ref is not None:                                        # min(p, p_ref_last), :598
+            lower = p_ref < new
+            new = np.where(lower, p_ref, new)
+            idx = np.where(lower, idx_last, idx)
+        if np.any(np.isnan(new)):                                    # :245-251
+            raise ValueError('No reference pressure level above the required local minimum pressure level '
+                             'could not be found everywhere.')
+        p_ref, idx_last = new, idx
+        hus_pgw = relative_to_specific_humidity(hur_pgw, pa_pgw, ta_pgw)
+        phi_ref_pgw = integ_geopot(pa_hl_pgw, FIS, ta_pgw, hus_pgw, level1, p_ref)
+        phi_ref_era = integ_geopot(pa_hl_era, FIS, T, QV, level1, p_ref)
+        sel = np.take_along_axis(np.asarray(dzg, dtype=np.float64), idx[:, None], axis=1)[:, 0]   # .sel(plev=p_ref), :294
+        phi_ref_error = (phi_ref_pgw - phi_ref_era) - sel * CON_G
+        adj_ps = - adj_factor * ps_pgw / (CON_RD * ta_pgw[:, n_lowest]) * phi_ref_error
+        a = np.abs(phi_ref_error)
+        phi_ref_max_error = np.nanmax(a) if not np.all(np.isnan(a)) else np.nan
+        hist.append(float(phi_ref_max_error))
+        it += 1
+        if it > max_n_iter:
+            raise ValueError('ERROR! Pressure adjustment did not converge')
+    return dict(ps_pgw=ps_pgw, hus_pgw=hus_pgw, delta_ps=delta_ps, n_iter=it - 1, max_err=hist, p_ref=p_ref)
+
+
 # ----------------------------------------------------------------------------------------
 # a10  regrid_lat_lon, xarray branch                                 functions.py:774-893
 # ----------------------------------------------------------------------------------------

@@ -88,11 +88,11 @@ SIGNATURES = {
 class FileArgs(C.Structure):
     """`pgw_file_args` of include/pgw_hip.h (whole-file entry pgw_step03_file)."""
     _fields_ = (
-        [(n, C.c_int) for n in ('dtype', 'ntime', 'nlev', 'nplev', 'nsoil', 'ignore_top', 'max_n_iter', '_pad0')] +
+        [(n, C.c_int) for n in ('dtype', 'ntime', 'nlev', 'nplev', 'nsoil', 'ignore_top', 'max_n_iter', 'local_p_ref')] +
         [('ncol', C.c_longlong)] +
         [(n, C.c_void_p) for n in ('PS', 'FIS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE')] +
         [('soil_depth', _dp), ('plev', _dp)] +
-        [(n, C.c_void_p) for n in ('ta_b', 'ta_a', 'hur_b', 'hur_a', 'ua_b', 'ua_a', 'va_b', 'va_a', 'zg_b', 'zg_a',
+        [(n, C.c_void_p) for n in ('ta_b', 'ta_a', 'hur_b', 'hur_a', 'ua_b', 'ua_a', 'va_b', 'va_a', 'zg_b', 'zg_a', 'zg3_b', 'zg3_a',
                                    'tas_b', 'tas_a', 'hurs_b', 'hurs_a', 'pshist_b', 'pshist_a',
                                    'siconc_b', 'siconc_a', 'ts_b', 'ts_a', 'tos_b', 'tos_a', 'ts_clim')] +
         [(n, C.c_double) for n in ('x_hi', 'x_new', 'p_ref', 'adj_factor', 'thresh')] +

@@ -83,6 +83,10 @@ static const char *status_text(int code) {
                    "--ignore_top_pressure_error and re-run the script.";
         case PGW_ERR_NOT_CONVERGED: return "ERROR! Pressure adjustment did not converge";
         case PGW_ERR_GRID_EXTENT: return "ERA5 dataset extends further than GCM dataset!";
+        case PGW_ERR_NO_P_REF:
+            return "No reference pressure level above the required local minimum pressure level could not be found "
+                   "everywhere. This is likely the case because your geopotential data set does not reach up high enough "
+                   "(e.g. only to 500 hPa instead of e.g. 300 hPa?)";
         default: return "error";
     }
 }
@@ -679,7 +683,7 @@ static int step_u() {
 static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *evap,
                        const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
                        double *delta_ps, double *adj_ps, double p_ref, const double *p_ref_field,
-                       double adj_factor, int full_column) {
+                       double adj_factor, int full_column, int apply_adj = 1) {
     int vec = pick_vec(dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field}, 2);
     // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
     Levels lv = levels_of(ctx);
@@ -688,23 +692,24 @@ static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, 2>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
                                                     dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
                                                     (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                    p_ref, p_ref_field, adj_factor, full_column, ctx->d_status));
+                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, ctx->d_status));
     else
         DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
                                                     dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
                                                     (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                    p_ref, p_ref_field, adj_factor, full_column, ctx->d_status));
+                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, ctx->d_status));
     return PGW_OK;
 }
 
 static int launch_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *hus,
-                                 const void *PS, const void *FIS, double p_ref, double *phi_out, int full_column) {
+                                 const void *PS, const void *FIS, double p_ref, double *phi_out, int full_column,
+                                 const double *p_ref_field = nullptr) {
     int vec = pick_vec(dtype, ncol, {ta, hus, PS, FIS, phi_out}, 2);
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_PHI_REF_HYBRID);
     DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_phi_ref_hybrid<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
                                                 dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)hus,
-                                                (const T *)PS, (const T *)FIS, p_ref, (const double *)nullptr, phi_out,
+                                                (const T *)PS, (const T *)FIS, p_ref, p_ref_field, phi_out,
                                                 full_column, ctx->d_status));
     return PGW_OK;
 }
@@ -760,28 +765,40 @@ extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long 
 // The loop of step_03_apply_to_era.py:182-319 given the iterate-independent vapour pressure
 // `evap` = hur_pgw/100 * e_sat(ta_pgw) (functions.py:123).  Shared by pgw_adjust_ps_loop and
 // pgw_step03_file.
+// local_nplev > 0 selects p_ref_inp = None (step_03:219-253): dzg_b/dzg_a are then the full
+// (ntime, nplev, ncol) zg records and `plev_file` the plev coordinate in file order.
 static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *PS, const void *FIS,
                        const void *T, const void *QV, const void *ta_pgw, const void *evap,
                        const void *dzg_b, const void *dzg_a, double x_hi, double x_new, double p_ref,
                        double adj_factor, double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
-                       double *max_err_hist, int hist_len) {
+                       double *max_err_hist, int hist_len, int local_nplev = 0, const double *plev_file = nullptr,
+                       const double *akbk_N = nullptr) {
     const long long n2 = (long long)ntime * ncol;
     void *state = nullptr;
     int rc;
-    if ((rc = ws_get(ctx, 1, (size_t)n2 * 4 * sizeof(double), &state))) return rc;
+    if ((rc = ws_get(ctx, 1, (size_t)n2 * 6 * sizeof(double), &state))) return rc;
     double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
+    double *pref_f = adj_ps + n2;
+    int *pref_idx = (int *)(pref_f + n2);
     const int full_column = full_column_env();
-
-    // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it)
-    if ((rc = status_reset(ctx))) return rc;
-    launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column);
-    HIPCHK(ctx, hipGetLastError());
-    if ((rc = status_check(ctx))) return rc;
-    // g * (time-interpolated zg delta at p_ref)   step_03:292-295
-    DISPATCH_T(dtype, {
-        DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
-        hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi);
-    });
+    const bool local = local_nplev > 0;
+    PlevTable ptf;
+    memset(&ptf, 0, sizeof(ptf));
+    if (local) {
+        ptf.n = local_nplev;
+        for (int i = 0; i < local_nplev; ++i) ptf.p[i] = plev_file[i];
+    } else {
+        // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it)
+        if ((rc = status_reset(ctx))) return rc;
+        launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column);
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = status_check(ctx))) return rc;
+        // g * (time-interpolated zg delta at p_ref)   step_03:292-295
+        DISPATCH_T(dtype, {
+            DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
+            hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi);
+        });
+    }
     HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
 
     double phi_ref_max_error = INFINITY;                                   // :186
@@ -789,8 +806,21 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     unsigned long long touched = 0;
     while (phi_ref_max_error > thresh) {                                   // :189
         if ((rc = status_reset(ctx))) return rc;
-        launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
-                    adj_factor, full_column);
+        if (local) {
+            // delta_ps += adj_ps ; per-column p_ref (never lower than last pass) ; g*zg at that level
+            DISPATCH_T(dtype, {
+                DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
+                hipLaunchKernelGGL((k_local_p_ref<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, ptf, akbk_N[0],
+                                   akbk_N[1], n2, (const T *)PS, delta_ps, adj_ps, z, ncol, it == 1 ? 1 : 0, pref_f,
+                                   pref_idx, dphi, ctx->d_status);
+            });
+            launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, 0.0, phi_era, full_column, pref_f);   // :280-287
+            launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, 0.0, pref_f,
+                        adj_factor, full_column, 0);
+        } else {
+            launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
+                        adj_factor, full_column);
+        }
         HIPCHK(ctx, hipGetLastError());
         if ((rc = status_check(ctx))) return rc;
         phi_ref_max_error = max_err_of(ctx);                               // :308
@@ -845,8 +875,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     NEED(ctx, ctx->nlev > 0 && a->nlev == ctx->nlev, "nlev must match pgw_set_levels");
     NEED(ctx, a->nplev >= 2 && a->nplev <= MAX_PLEV, "nplev must be in [2, 64]");
     NEED(ctx, a->PS && a->FIS && a->T && a->QV && a->U && a->V, "ERA5 field pointer is NULL");
-    NEED(ctx, a->plev && a->ta_b && a->hur_b && a->ua_b && a->va_b && a->zg_b && a->tas_b && a->hurs_b && a->pshist_b,
-         "delta record pointer is NULL");
+    NEED(ctx, a->plev && a->ta_b && a->hur_b && a->ua_b && a->va_b && (a->zg_b || a->local_p_ref) && a->tas_b && a->hurs_b &&
+         a->pshist_b, "delta record pointer is NULL");
     NEED(ctx, a->PS_out && a->T_out && a->QV_out && a->U_out && a->V_out, "output pointer is NULL");
     NEED(ctx, a->max_n_iter >= 1 && a->max_n_iter <= 1000, "bad max_n_iter");
     const bool exact = (a->x_hi == 0.0);
@@ -959,9 +989,18 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     // ---- fixed-point loop + final PS, QV
     a->n_iter = 0;
     for (int i = 0; i < 32; ++i) a->max_err_hist[i] = NAN;
-    rc = run_ps_loop(ctx, dtype, ntime, ncol, a->PS, a->FIS, a->T, a->QV, a->T_out, evap, a->zg_b, a->zg_a, a->x_hi,
+    double akbk_N[2] = {0.0, 0.0};
+    if (a->local_p_ref) {
+        NEED(ctx, a->zg3_b != nullptr, "local_p_ref needs the full zg records (zg3_b / zg3_a)");
+        std::vector<double> h(2);
+        HIPCHK(ctx, hipMemcpyAsync(&akbk_N[0], ctx->d_levels + N, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&akbk_N[1], ctx->d_levels + (N + 1) + N, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    rc = run_ps_loop(ctx, dtype, ntime, ncol, a->PS, a->FIS, a->T, a->QV, a->T_out, evap,
+                     a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a, a->x_hi,
                      a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
-                     a->max_err_hist, 32);
+                     a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev, akbk_N);
     a->levels_touched = ctx->last_levels_touched;
     return rc;
 }

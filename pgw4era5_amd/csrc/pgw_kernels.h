@@ -339,7 +339,8 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
                                                           const double *__restrict__ dphi_clim,
                                                           double *__restrict__ delta_ps, double *__restrict__ adj_ps,
                                                           double p_ref_s, const double *__restrict__ p_ref_f,
-                                                          double adj_factor, int full_column, DevStatus *st) {
+                                                          double adj_factor, int full_column, int apply_adj,
+                                                          DevStatus *st) {
     __shared__ double s_max[BLOCK / 64];
     __shared__ unsigned int s_valid[BLOCK / 64];
     __shared__ double s_lev[LEVTAB_DOUBLES];
@@ -364,10 +365,10 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            dps[v] = dps[v] + adj[v];                       // step_03:192
+            if (apply_adj) dps[v] = dps[v] + adj[v];        // step_03:192 (already applied by k_local_p_ref otherwise)
             ps[v] = ps0[v] + dps[v];                        // :193
         }
-        storev<double, V>(delta_ps + c2, dps);
+        if (apply_adj) storev<double, V>(delta_ps + c2, dps);
         scan_columns<T, V, U, false>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, evap + ix.t * N * ncol + ix.c, ps, z, pref,
                                      full_column, st, c2, phi_ref, tlow, touched);
         double nadj[V];
@@ -1137,6 +1138,39 @@ __global__ __launch_bounds__(BLOCK) void k_integrate_tos(long long n, const T *_
         r = fr * s + (1 - fr) * o;                                  // :1184
     }
     out[i] = (T)r;
+}
+
+// p_ref_inp = None (step_03:219-253 with determine_p_ref, functions.py:583-598): per column the first
+// plev (file order) with 0.95*ps_era > p and 0.95*ps_pgw > p, never below the previous pass's choice;
+// also applies delta_ps += adj_ps (step_03:192) and gathers g * zg-delta at the chosen level (:292-295).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_local_p_ref(PlevTable pt /* p[] in FILE order here */, double akN, double bkN,
+                                                       long long n, const T *__restrict__ PS,
+                                                       double *__restrict__ delta_ps, const double *__restrict__ adj_ps,
+                                                       DeltaSrc<T> zg /* (nplev, ncol) records */, long long ncol, int first_pass,
+                                                       double *__restrict__ p_ref, int *__restrict__ p_idx,
+                                                       double *__restrict__ dphi, DevStatus *st) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double dps = delta_ps[i] + adj_ps[i];                           // step_03:192
+    delta_ps[i] = dps;
+    double ps0 = (double)PS[i];
+    double p_min_era = (akN + ps0 * bkN) * 0.95;                    // :227-228
+    double p_min_pgw = (akN + (ps0 + dps) * bkN) * 0.95;            // :229-230
+    double p = __builtin_nan("");
+    int k = -1;
+    for (int j = 0; j < pt.n; ++j) {
+        if ((p_min_era > pt.p[j]) && (p_min_pgw > pt.p[j])) { p = pt.p[j]; k = j; break; }   // functions.py:593-596
+    }
+    if (k >= 0 && !first_pass) {
+        double last = p_ref[i];
+        if (last < p) { p = last; k = p_idx[i]; }                    // min(p, p_ref_last)  :598
+    }
+    if (k < 0) { report(st, 19, i); p_ref[i] = p; p_idx[i] = -1; dphi[i] = p; return; }   // step_03:245-251
+    p_ref[i] = p;
+    p_idx[i] = k;
+    long long t = i / ncol, c = i - t * ncol;
+    dphi[i] = zg.get((t * pt.n + k) * ncol + c) * CON_G;            // step_03:292-295
 }
 
 // g * time-interpolated zg delta at p_ref -> fp64 loop constant (step_03:292-295)

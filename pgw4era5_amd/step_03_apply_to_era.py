@@ -141,7 +141,9 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     deltas: DeltaSet.  out: optional dict of preallocated output DeviceArrays (reused
     across files).  Returns (dict of DeviceArrays, info)."""
     lib, h = ctx.lib, ctx.handle
-    p_ref = S.p_ref_inp if p_ref is None else p_ref
+    if p_ref is None:
+        p_ref = S.p_ref_inp
+    local_p_ref = (p_ref is None) or (p_ref == 'local')          # settings.p_ref_inp = None, step_03:219-253
     dt = deltas.dtype
     ctx.set_levels(coeffs['ak'], coeffs['bk'], coeffs.get('akm'), coeffs.get('bkm'))
     T, PS = era['T'], era['PS']
@@ -156,14 +158,21 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)           # functions.py:224-283
     rb, ra = int(keep[ib]), int(keep[ia])
     plev = deltas.plev
-    kref = np.nonzero(plev == p_ref)[0]                             # .sel(plev=p_ref), step_03:294
-    if len(kref) != 1:
-        raise KeyError(p_ref)
     a = _lib.FileArgs()
+    if local_p_ref:
+        a.local_p_ref = 1
+        a.zg3_b, a.zg3_a = deltas.dev['zg'].slab(rb).ptr, deltas.dev['zg'].slab(ra).ptr
+    else:
+        kref = np.nonzero(plev == p_ref)[0]                         # .sel(plev=p_ref), step_03:294
+        if len(kref) != 1:
+            raise KeyError(p_ref)
+        a.zg_b = deltas.dev['zg'].slab(rb).slab(int(kref[0])).ptr
+        a.zg_a = deltas.dev['zg'].slab(ra).slab(int(kref[0])).ptr
+        a.p_ref = float(p_ref)
     a.dtype, a.ntime, a.nlev, a.nplev, a.ncol = dtype_tag(dt), nt, N, len(plev), nlat * nlon
     a.ignore_top = 1 if ignore_top_pressure_error else 0
     a.max_n_iter = int(S.max_n_iter)
-    a.p_ref, a.adj_factor, a.thresh = float(p_ref), float(S.adj_factor), float(S.thresh_phi_ref_max_error)
+    a.adj_factor, a.thresh = float(S.adj_factor), float(S.thresh_phi_ref_max_error)
     a.x_hi, a.x_new = x_hi, x_new
     for k in ('PS', 'FIS', 'T', 'QV', 'U', 'V'):
         setattr(a, k, era[k].ptr)
@@ -172,8 +181,6 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     for var in ('ta', 'hur', 'ua', 'va'):
         setattr(a, var + '_b', dev[var].slab(rb).ptr)
         setattr(a, var + '_a', dev[var].slab(ra).ptr)
-    a.zg_b = dev['zg'].slab(rb).slab(int(kref[0])).ptr
-    a.zg_a = dev['zg'].slab(ra).slab(int(kref[0])).ptr
     for var, name in (('tas', 'tas'), ('hurs', 'hurs'), ('ps_hist', 'pshist')):
         setattr(a, name + '_b', dev[var].slab(rb).ptr)
         setattr(a, name + '_a', dev[var].slab(ra).ptr)
@@ -261,8 +268,8 @@ def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step
     if debug_mode is not None:
         raise NotImplementedError('debug_mode (step_03_apply_to_era.py:350-361, 387-414) is a validation aid of '
                                   'the reference and not part of the MI355X hot path')
-    if S.i_reinterp or S.p_ref_inp is None:
-        raise NotImplementedError('i_reinterp = 1 and p_ref_inp = None are not built yet (SURVEY.md section 8 f)')
+    if S.i_reinterp:
+        raise NotImplementedError('i_reinterp = 1 is not built yet (SURVEY.md section 8 f)')
     if S.i_debug >= 0:
         print('Start working on input file {}'.format(inp_era_file_path))
     ctx = default_context()
@@ -286,7 +293,8 @@ def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step
         coeffs['bkm'] = np.asarray(era_file['bkm'].values, dtype=np.float64)
     deltas = load_delta_set(ctx, delta_input_dir, dtype)
     e = _upload_era(ctx, era, dtype)
-    out, info = process_file_device(ctx, e, coeffs, deltas, era_step_dt, ignore_top_pressure_error)
+    out, info = process_file_device(ctx, e, coeffs, deltas, era_step_dt, ignore_top_pressure_error,
+                                    p_ref='local' if S.p_ref_inp is None else S.p_ref_inp)
     if S.i_debug >= 2:
         for it, err in enumerate(info['max_err']):
             print('### iteration {:03d}, phi max error: {}'.format(it + 1, err))

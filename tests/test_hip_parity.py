@@ -438,3 +438,46 @@ def test_full_size_analytic_and_linearity(full_case):
     b = F.vert_interp_delta(d2, pa, None, None, True, plev=case['plev']).numpy()
     c = F.vert_interp_delta(2.0 * d1 - 0.5 * d2, pa, None, None, True, plev=case['plev']).numpy()
     np.testing.assert_allclose(c, 2.0 * a - 0.5 * b, rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ p_ref_inp = None (SURVEY 8 f, rank 2)
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_local_p_ref_mode_vs_oracle(dtype):
+    """settings.p_ref_inp = None: reference pressure chosen per column and per pass
+    (reference step_03_apply_to_era.py:219-253, functions.py:583-598)."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c = _case(9, 14, 30, seed=21, dtype=dtype)
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref='local')
+    f64 = lambda x: np.asarray(x, dtype=np.float64)
+    era = {k: (f64(v) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in c['era'].items()}
+    d = {k: f64(v) for k, v in c['deltas'].items()}
+    akm, bkm = O.full_level_coeffs(era['ak'], era['bk'])
+    _, pa = O.hybrid_pressure(era['ak'], era['bk'], era['PS'], akm, bkm)
+    ld = lambda k: O.load_delta_values(d[k], c['delta_times'], c['target_dt'])
+    ta = era['T'] + O.vert_interp_delta(ld('ta'), c['plev'], pa, ld('tas'), ld('ps_hist'), True)
+    hur = O.specific_to_relative_humidity(era['QV'], pa, era['T']) + \
+        O.vert_interp_delta(ld('hur'), c['plev'], pa, ld('hurs'), ld('ps_hist'), True)
+    want = O.adjust_ps_loop_local_pref(era['ak'], era['bk'], akm, bkm, era['PS'], era['FIS'], era['T'], era['QV'],
+                                       ta, hur, ld('zg'), c['plev'])
+    assert len(np.unique(want['p_ref'])) > 1            # mountains pick a higher reference level than sea points
+    assert got['n_iter'] == want['n_iter']
+    tol = 1e-9 if dtype == np.float64 else 1e-6
+    np.testing.assert_allclose(got['PS'], want['ps_pgw'], rtol=tol)
+    np.testing.assert_allclose(got['QV'], want['hus_pgw'], rtol=tol if dtype == np.float64 else 3e-6, atol=1e-18)
+    np.testing.assert_allclose(got['max_err'], want['max_err'], rtol=1e-6 if dtype == np.float64 else 1e-5, atol=1e-7)
+
+
+def test_local_p_ref_no_candidate_error():
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c = _case(4, 5, 12, seed=22)
+    keep = c['plev'] >= 85000.0                      # deltas that only reach 850 hPa
+    d = {k: (v[:, keep] if v.ndim == 4 else v.copy()) for k, v in c['deltas'].items()}
+    # every column above the delta top (ps_hist > 850 hPa, else replace_delta_sfc raises first), but one
+    # column with 0.95 * ps below 850 hPa: no reference level for it
+    c['era']['PS'][:] = np.maximum(c['era']['PS'], 95000.0)
+    d['ps_hist'][:] = np.maximum(d['ps_hist'], 95000.0)
+    c['era']['PS'][0, 0, 0] = 88000.0
+    d['ps_hist'][:, 0, 0] = 88000.0
+    with pytest.raises(ValueError) as e:
+        s3.pgw_for_era5_arrays(c['era'], d, c['delta_times'], c['plev'][keep], c['target_dt'], True, p_ref='local')
+    assert 'No reference pressure level' in str(e.value)
