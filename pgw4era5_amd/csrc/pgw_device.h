@@ -104,29 +104,30 @@ __device__ __forceinline__ double esat_ice(double ta) {     // :74-89 ice (a4 = 
 // alpha*e_w + (1-alpha)*e_i is evaluated in full only in the mixed range; for alpha in {0,1}
 // the dropped term is exactly 0*finite = 0 for every finite T (e_w, e_i are finite for all
 // T > 32.19 K), so the value is unchanged.
-// Each exp sits behind a real branch (no_speculate): the regimes are wave-uniform over most of
-// the atmosphere, so a wave pays for one exp + one division outside the mixed range.
+// One unconditional division + exp evaluates the phase every temperature needs (water for
+// T >= T0, ice otherwise; the coefficients are selected, not the results), and only lanes in the
+// mixed range take a real branch (no_speculate) for the second one.
 __device__ __forceinline__ double esat_mixed(double ta) {
     const double T0 = 273.16, Ti = 250.16;
-    double ew = 0.0, ei = 0.0;
-    const bool cold = (ta <= Ti), warm = (ta >= T0);
-    if (!cold || !(ta > 40.0)) {                                // water term needed (also NaN / unphysical cold)
-        ew = esat_water(no_speculate(ta));
+    const bool warm = (ta >= T0);
+    const double a3 = warm ? 17.502 : 22.587;
+    const double a4 = warm ? 32.19 : -0.7;
+    double e1 = 611.21 * exp(a3 * (ta - T0) / (ta - a4));        // e_w if warm else e_i (NaN for NaN ta)
+    if (warm) return e1;
+    if (ta <= Ti) {
+        if (__builtin_expect(!(ta > 40.0), 0)) {                 // unphysical cold: literal expression, 0*e_w may be NaN/inf
+            double ew = esat_water(no_speculate(ta));
+            return 0.0 * ew + 1.0 * e1;
+        }
+        return e1;
     }
-    if (!warm) {                                                // ice term needed (also NaN)
-        ei = esat_ice(no_speculate(ta));
-    }
-    if (warm) return ew;
-    if (cold) {
-        if (ta > 40.0) return ei;
-        return 0.0 * ew + 1.0 * ei;                             // unphysical cold: literal expression (0*e_w may be NaN/inf)
-    }
-    if (ta < T0 && ta > Ti) {
+    if (ta < T0 && ta > Ti) {                                    // mixed phase
+        double ew = esat_water(no_speculate(ta));
         double r = (ta - Ti) / (T0 - Ti);
-        double alpha = r * r;                                   // np.power(x, 2.) == x*x
-        return alpha * ew + (1 - alpha) * ei;
+        double alpha = r * r;                                    // np.power(x, 2.) == x*x
+        return alpha * ew + (1 - alpha) * e1;
     }
-    return __builtin_nan("");                                   // NaN temperature
+    return __builtin_nan("");                                    // NaN temperature
 }
 __device__ __forceinline__ double q_to_e(double hus, double pa) {          // :58-64
     return hus * pa / (CON_MW_MD + 0.378 * hus);
