@@ -35,11 +35,69 @@ def _merge(fargs, step_args):
     return tasks
 
 
+def run_shard(func, tasks, indices, depth=2):
+    """Run `func(**tasks[i])` for i in indices on this rank.  If `func.stages = (load, compute,
+    store)` exists, the three stages run as a pipeline: a reader thread stays up to `depth` files
+    ahead (host I/O), this thread does the GPU stage, a writer thread stores results - so file
+    reads and writes overlap the device work (the reference does them serially per worker)."""
+    stages = getattr(func, 'stages', None)
+    if not stages or len(indices) < 2:
+        return [(i, func(**tasks[i])) for i in indices]
+    import queue
+    import threading
+    load, compute, store = stages
+    q_in, q_out = queue.Queue(maxsize=depth), queue.Queue(maxsize=depth)
+    results, errors = {}, []
+
+    def reader():
+        try:
+            for i in indices:
+                if errors:
+                    break
+                q_in.put((i, load(**tasks[i])))
+        except BaseException as e:      # noqa: BLE001
+            errors.append(e)
+        finally:
+            q_in.put(None)
+
+    def writer():
+        while True:
+            item = q_out.get()
+            if item is None:
+                return
+            try:
+                results[item[0]] = store(item[1])
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+    tr, tw = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
+    tr.start(); tw.start()
+    try:
+        while True:
+            item = q_in.get()
+            if item is None or errors:
+                break
+            q_out.put((item[0], compute(item[1])))
+    except BaseException as e:          # noqa: BLE001
+        errors.append(e)
+    finally:
+        while tr.is_alive():            # unblock a reader waiting on a full queue
+            try:
+                q_in.get_nowait()
+            except queue.Empty:
+                tr.join(timeout=0.05)
+        q_out.put(None)
+        tw.join()
+    if errors:
+        raise errors[0]
+    return [(i, results[i]) for i in indices]
+
+
 def _worker(rank, world, func, tasks, queue):
     os.environ['LOCAL_RANK'] = str(rank)
     os.environ['PGW_RANK'] = str(rank)
     try:
-        out = [(i, func(**tasks[i])) for i in shard_indices(len(tasks), rank, world)]
+        out = run_shard(func, tasks, shard_indices(len(tasks), rank, world))
         queue.put((rank, out, None))
     except BaseException as e:   # noqa: BLE001 - reported to the parent, which re-raises
         queue.put((rank, [], '%s: %s' % (type(e).__name__, e)))
@@ -72,7 +130,7 @@ class IterMP:
         elif self.njobs > 1 and len(tasks) > 1:
             self.output = self._run_spawn(func, tasks, min(self.njobs, len(tasks)))
         else:
-            self.output = [func(**kw) for kw in tasks]
+            self.output = [r for _, r in run_shard(func, tasks, list(range(len(tasks))))]
         return self.output
 
     # one process per GPU, launched by torchrun
@@ -89,7 +147,7 @@ class IterMP:
         err = None
         mine = []
         try:
-            mine = [(i, func(**tasks[i])) for i in shard_indices(len(tasks), rank, world)]
+            mine = run_shard(func, tasks, shard_indices(len(tasks), rank, world))
         except Exception as e:            # noqa: BLE001 - every rank must reach the gather
             err = '%s: %s' % (type(e).__name__, e)
         gathered = [None] * world

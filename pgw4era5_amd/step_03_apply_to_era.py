@@ -261,9 +261,9 @@ def load_delta_set(ctx, delta_input_dir, dtype):
     return dset
 
 
-def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt,
-                 ignore_top_pressure_error, debug_mode=None):
-    """Apply the PGW deltas to one ERA5 file (reference step_03_apply_to_era.py:44-381)."""
+def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt,
+                ignore_top_pressure_error, debug_mode=None):
+    """Stage 1 (host, I/O): read one ERA5 file and lay its fields out as C-order host arrays."""
     from . import ncio
     if debug_mode is not None:
         raise NotImplementedError('debug_mode (step_03_apply_to_era.py:350-361, 387-414) is a validation aid of '
@@ -272,43 +272,82 @@ def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step
         raise NotImplementedError('i_reinterp = 1 is not built yet (SURVEY.md section 8 f)')
     if S.i_debug >= 0:
         print('Start working on input file {}'.format(inp_era_file_path))
-    ctx = default_context()
     era_file = ncio.open_dataset(inp_era_file_path, decode_times=False)      # step_03:60
     vm = S.var_name_map
     dtype = np.dtype('float64') if era_file[vm['ta']].dtype == np.float64 else np.dtype('float32')
     dims4 = (S.TIME_ERA, S.LEV_ERA, S.LAT_ERA, S.LON_ERA)
     dims3 = (S.TIME_ERA, S.LAT_ERA, S.LON_ERA)
+    dims_so = (S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA)
 
     def get(name, dims):
         return np.ascontiguousarray(era_file[name].transpose(*dims).values, dtype=dtype)
 
     era = dict(PS=get(vm['ps'], dims3), FIS=get(vm['zgs'], dims3), T=get(vm['ta'], dims4), QV=get(vm['hus'], dims4),
                U=get(vm['ua'], dims4), V=get(vm['va'], dims4), T_SKIN=get(vm['ts'], dims3),
-               T_SO=get(vm['st'], (S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA)),
-               FR_LAND=get(vm['sftlf'], dims3), FR_SEA_ICE=get(vm['sic'], dims3))
+               T_SO=get(vm['st'], dims_so), FR_LAND=get(vm['sftlf'], dims3), FR_SEA_ICE=get(vm['sic'], dims3))
     coeffs = dict(ak=np.asarray(era_file['ak'].values, dtype=np.float64), bk=np.asarray(era_file['bk'].values, dtype=np.float64),
                   soil1=np.asarray(era_file[S.SOIL_HLEV_ERA].values, dtype=np.float64))
     if 'akm' in era_file:                                                    # step_03:68-70
         coeffs['akm'] = np.asarray(era_file['akm'].values, dtype=np.float64)
         coeffs['bkm'] = np.asarray(era_file['bkm'].values, dtype=np.float64)
-    deltas = load_delta_set(ctx, delta_input_dir, dtype)
-    e = _upload_era(ctx, era, dtype)
-    out, info = process_file_device(ctx, e, coeffs, deltas, era_step_dt, ignore_top_pressure_error,
-                                    p_ref='local' if S.p_ref_inp is None else S.p_ref_inp)
+    return dict(era_file=era_file, era=era, coeffs=coeffs, dtype=dtype, out_path=out_era_file_path,
+                delta_input_dir=delta_input_dir, era_step_dt=era_step_dt, ignore_top=ignore_top_pressure_error,
+                dims=dict(d3=dims3, d4=dims4, so=dims_so))
+
+
+_DEVICE_BUFFERS = {}
+
+
+def _stage_compute(item):
+    """Stage 2 (GPU): upload, one pgw_step03_file call, download.  Device buffers of a given
+    shape/dtype are reused from file to file."""
+    ctx = default_context()
+    dtype = item['dtype']
+    deltas = load_delta_set(ctx, item['delta_input_dir'], dtype)
+    key = (item['era']['T'].shape, dtype.str)
+    bufs = _DEVICE_BUFFERS.setdefault(key, dict(inp={}, out={}))
+    for k, v in item['era'].items():
+        if k not in bufs['inp']:
+            bufs['inp'][k] = ctx.empty(v.shape, dtype)
+        bufs['inp'][k].copy_from(v)
+    out, info = process_file_device(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
+                                    p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
+    item['result'] = {k: out[k].numpy() for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE')}
+    item['info'] = info
+    item['era'] = None                                  # release the host copies of the inputs
     if S.i_debug >= 2:
         for it, err in enumerate(info['max_err']):
             print('### iteration {:03d}, phi max error: {}'.format(it + 1, err))
-    # write back (step_03:369-378): PS, T, QV, U, V (+ T_SKIN, T_SO, FR_SEA_ICE updated in place :105-144)
-    names = dict(PS=(vm['ps'], dims3), T=(vm['ta'], dims4), QV=(vm['hus'], dims4), U=(vm['ua'], dims4), V=(vm['va'], dims4),
-                 T_SKIN=(vm['ts'], dims3), T_SO=(vm['st'], (S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA)),
-                 FR_SEA_ICE=(vm['sic'], dims3))
+    return item
+
+
+def _stage_store(item):
+    """Stage 3 (host, I/O): write the modified file (step_03:369-378: PS, T, QV, U, V; T_SKIN, T_SO and
+    FR_SEA_ICE were updated in place at :105-144; RELHUM is never added)."""
+    from . import ncio
+    era_file, vm, d = item['era_file'], S.var_name_map, item['dims']
+    names = dict(PS=(vm['ps'], d['d3']), T=(vm['ta'], d['d4']), QV=(vm['hus'], d['d4']), U=(vm['ua'], d['d4']),
+                 V=(vm['va'], d['d4']), T_SKIN=(vm['ts'], d['d3']), T_SO=(vm['st'], d['so']), FR_SEA_ICE=(vm['sic'], d['d3']))
     for key, (name, dims) in names.items():
         old = era_file[name]
-        era_file[name] = ncio.Field(out[key].numpy(), dims, {d: old.coords[d] for d in dims if d in old.coords}, old.attrs)
-    ncio.to_netcdf(era_file, out_era_file_path)
+        era_file[name] = ncio.Field(item['result'][key], dims, {k: old.coords[k] for k in dims if k in old.coords}, old.attrs)
+    ncio.to_netcdf(era_file, item['out_path'])
     if S.i_debug >= 1:
-        print('Done. Saved to file {}.'.format(out_era_file_path))
-    return info['n_iter']
+        print('Done. Saved to file {}.'.format(item['out_path']))
+    return item['info']['n_iter']
+
+
+def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt,
+                 ignore_top_pressure_error, debug_mode=None):
+    """Apply the PGW deltas to one ERA5 file (reference step_03_apply_to_era.py:44-381).
+    Returns the number of loop passes.  When many files are processed through IterMP the three
+    stages below run as a pipeline (read of file i+1 and write of file i-1 overlap the GPU work of
+    file i; SURVEY.md section 8 f rank 1)."""
+    return _stage_store(_stage_compute(_stage_load(inp_era_file_path, out_era_file_path, delta_input_dir,
+                                                   era_step_dt, ignore_top_pressure_error, debug_mode)))
+
+
+pgw_for_era5.stages = (_stage_load, _stage_compute, _stage_store)
 
 
 def _cli(argv=None):

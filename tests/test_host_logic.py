@@ -188,3 +188,53 @@ def test_cli_argument_surface():
     assert str(e.value) == 'era5_file_path is required for regridding step.'
     with pytest.raises(SystemExit):
         s2.main(['frobnicate'])
+
+
+def test_pipelined_shard_overlaps_stages_and_keeps_order():
+    """IterMP runs func.stages = (load, compute, store) as a 3-stage pipeline per rank."""
+    import threading
+    import time
+    from pgw4era5_amd.parallel import run_shard, IterMP
+    log = []
+    lock = threading.Lock()
+
+    def load(x):
+        time.sleep(0.05)
+        with lock:
+            log.append(('load', x))
+        return dict(x=x)
+
+    def compute(item):
+        with lock:
+            log.append(('compute', item['x']))
+        time.sleep(0.02)
+        item['y'] = item['x'] * 10
+        return item
+
+    def store(item):
+        time.sleep(0.05)
+        with lock:
+            log.append(('store', item['x']))
+        return item['y']
+
+    def func(x):
+        return store(compute(load(x)))
+    func.stages = (load, compute, store)
+    tasks = [dict(x=i) for i in range(6)]
+    t0 = time.time()
+    out = run_shard(func, tasks, list(range(6)))
+    el = time.time() - t0
+    assert out == [(i, i * 10) for i in range(6)]
+    assert el < 6 * 0.12 * 0.85                      # faster than the serial 6 x (0.05 + 0.02 + 0.05)
+    assert any(log.index(('load', i + 1)) < log.index(('store', i)) for i in range(5))   # reader runs ahead of the writer
+    imp = IterMP(njobs=1)
+    imp.run(func, {}, tasks)
+    assert imp.output == [i * 10 for i in range(6)]
+
+    def bad_compute(item):
+        if item['x'] == 3:
+            raise ValueError('boom')
+        return compute(item)
+    func.stages = (load, bad_compute, store)
+    with pytest.raises(ValueError):
+        run_shard(func, tasks, list(range(6)))

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""End-to-end timing of the step_03 command line INCLUDING file I/O (not the bench.py metric):
+writes K synthetic 0.25 deg L137 ERA5 files + the delta directory as NetCDF-3, runs
+`python -m pgw4era5_amd.step_03_apply_to_era` over them in this process and reports seconds per
+file for (a) the pipelined launcher and (b) the three stages run serially.
+
+    python tools/e2e_cli.py [--files 3] [--nlat 721 --nlon 1440 --nlev 137] [--dir /tmp/pgw_e2e]
+"""
+import argparse
+import datetime as dt
+import json
+import os
+import shutil
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--files', type=int, default=3)
+    p.add_argument('--nlat', type=int, default=721)
+    p.add_argument('--nlon', type=int, default=1440)
+    p.add_argument('--nlev', type=int, default=137)
+    p.add_argument('--dir', default='/tmp/pgw_e2e')
+    a = p.parse_args()
+    import numpy as np
+    from pgw4era5_amd import synthetic, step_03_apply_to_era as s3, settings as S
+    S.i_debug = 0
+    shutil.rmtree(a.dir, ignore_errors=True)
+    t0 = time.time()
+    case = synthetic.make_case(a.nlat, a.nlon, a.nlev, seed=1, dtype=np.float32)
+    first = dt.datetime(2006, 8, 2, 0)
+    for i in range(a.files):
+        case['target_dt'] = first + dt.timedelta(hours=i)
+        synthetic.write_case_files(case, os.path.join(a.dir, 'era'), os.path.join(a.dir, 'deltas'))
+    t_write = time.time() - t0
+    size = os.path.getsize(os.path.join(a.dir, 'era', S.era5_file_name_base.format(first)))
+    last = first + dt.timedelta(hours=a.files - 1)
+    argv = ['-i', os.path.join(a.dir, 'era'), '-o', os.path.join(a.dir, 'out'), '-d', os.path.join(a.dir, 'deltas'),
+            '-f', first.strftime('%Y%m%d%H'), '-l', last.strftime('%Y%m%d%H'), '-H', '1', '-p', '1', '-t']
+    t0 = time.time()
+    s3.load_delta_set(s3.default_context(), os.path.join(a.dir, 'deltas'), np.float32)      # once per run
+    t_deltas = time.time() - t0
+    t0 = time.time()
+    n_iter = s3._cli(argv)
+    t_pipe = time.time() - t0
+    # serial stages, timed individually on the first file
+    kw = dict(inp_era_file_path=os.path.join(a.dir, 'era', S.era5_file_name_base.format(first)),
+              out_era_file_path=os.path.join(a.dir, 'out', 'serial.nc'), delta_input_dir=os.path.join(a.dir, 'deltas'),
+              era_step_dt=first, ignore_top_pressure_error=True)
+    t0 = time.time(); item = s3._stage_load(**kw); t_load = time.time() - t0
+    t0 = time.time(); item = s3._stage_compute(item); t_comp = time.time() - t0
+    t0 = time.time(); s3._stage_store(item); t_store = time.time() - t0
+    print(json.dumps(dict(files=a.files, file_GB=round(size / 1e9, 3), n_iter=n_iter,
+                          setup_write_s=round(t_write, 1), delta_load_s=round(t_deltas, 2),
+                          pipelined_s_per_file=round(t_pipe / a.files, 2),
+                          serial_stage_s=dict(read=round(t_load, 2), upload_compute_download=round(t_comp, 2), write=round(t_store, 2)),
+                          files_per_hour_one_rank=round(3600.0 / (t_pipe / a.files), 1))))
+    shutil.rmtree(a.dir, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    main()
