@@ -939,14 +939,14 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
 #define LAUNCH_PAIR(THERMO, TPB, FA, FB, D3, DS, PH, OA, OB, OH)                                                      \
     do {                                                                                                               \
         if (lds > 64 * 1024)                                                                                           \
-            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_delta_pair<T, 1, THERMO, PAIR_U, TPB, true>,               \
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), TPB, true>,               \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
         if (staged)                                                                                                    \
-        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, PAIR_U, TPB, true>), dim3(grid), dim3(TPB), lds, ctx->stream,   \
+        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), TPB, true>), dim3(grid), dim3(TPB), lds, ctx->stream,   \
                            ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
                            ctx->d_status);                                                                             \
         else                                                                                                           \
-        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, PAIR_U, TPB, false>), dim3(grid), dim3(TPB), lds, ctx->stream,  \
+        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), TPB, false>), dim3(grid), dim3(TPB), lds, ctx->stream,  \
                            ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
                            ctx->d_status);                                                                             \
     } while (0)

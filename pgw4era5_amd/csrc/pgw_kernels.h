@@ -742,8 +742,10 @@ struct PairSrc {       // the two variables of a pair
 // are staged ONCE in LDS, laid out [level][thread] (conflict-free for any per-lane level index),
 // so the level loop does no global gathers: a gather's `s_waitcnt vmcnt(0)` would also wait for
 // the prefetched rows and all earlier stores and serialise the whole pipeline.
+// THERMO: 4 waves/SIMD (VGPR <= 128) with 2-level chunks measured 6 % faster than 3 waves with 4-level
+// chunks (fp64-VALU/latency bound); the wind pair is HBM bound and prefers the deeper prefetch.
 template <typename T, int V, bool THERMO, int U, int TPB, bool STAGED>
-__global__ __launch_bounds__(TPB) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
+__global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                     const T *__restrict__ fa, const T *__restrict__ fb,
                                                     const T *__restrict__ PS,
                                                     PairSrc<T> d3, PairSrc<T> dsfc, DeltaSrc<T> psh,
