@@ -334,7 +334,23 @@ def microbench(ctx, era, coeffs, a, np, reps=5):
         ctx._check(ctx.lib.pgw_pressure_levels(ctx.handle, tag, nt, ncol, era['PS'].ptr, pa_hl.ptr, pa.ptr))
         ctx._check(ctx.lib.pgw_integ_geopot(ctx.handle, tag, nt, N, ncol, pa_hl.ptr, era['FIS'].ptr, era['T'].ptr,
                                             era['QV'].ptr, 30000.0, None, phi.ptr, 1))
-    for name, nbytes in (('integ_geopot', (3 * N + 3) * ncol * s), ('pressure', (2 * N + 2) * ncol * s)):
+    # interp_logp_4d (functions.py:434-580), signature-faithful: var, source_P (S levels) and targ_P in, N levels out
+    S = 19
+    lev = np.linspace(1, N, S).round().astype(int)
+    src_p = ctx.empty((nt, S, nlat, nlon), dt)
+    src_v = ctx.empty((nt, S, nlat, nlon), dt)
+    plane = nlat * nlon * s
+    for k, l in enumerate(lev):          # S half levels of every column as an ascending source axis
+        ctx._check(ctx.lib.pgw_memcpy_d2d(ctx.handle, src_p.ptr + k * plane, pa_hl.ptr + int(l) * plane, plane))
+        ctx._check(ctx.lib.pgw_memcpy_d2d(ctx.handle, src_v.ptr + k * plane, era['T'].ptr + int(l - 1) * plane, plane))
+    interp_out = ctx.empty((nt, N, nlat, nlon), dt)
+    for _ in range(reps + 1):
+        ctx._check(ctx.lib.pgw_interp_logp_4d(ctx.handle, tag, nt, S, N, ncol, src_v.ptr, src_p.ptr, pa.ptr, 2, 0,
+                                              interp_out.ptr))
+    for x in (src_p, src_v, interp_out):
+        x.free()
+    for name, nbytes in (('integ_geopot', (3 * N + 3) * ncol * s), ('pressure', (2 * N + 2) * ncol * s),
+                         ('interp_logp', (2 * S + 2 * N) * ncol * s)):
         cnt, ms = ctx.profile_get(name)
         avg = ms / cnt
         out[name] = dict(launches=cnt, avg_ms=round(avg, 4), algo_GB=round(nbytes / 1e9, 4),

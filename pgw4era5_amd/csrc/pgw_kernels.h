@@ -536,21 +536,38 @@ __global__ __launch_bounds__(TPB) void k_interp_logp(int ntime, int S, int N, lo
     if (x_last < x_first) { report(st, 11, flat); }              // :502-503
     int j = 0;
     double xprev = -__builtin_inf();
-#pragma unroll 4
-    for (int l = 0; l < N; ++l) {
-        double x = (double)pt[(long long)l * ncol];
-        if (!logp_in) x = pgw_log(x);                                // :471
-        if (!(x >= xprev)) j = 0;                                // restart (descending or NaN)
-        while (j < S) {
-            double xs = sx[j * TPB];
-            if (xs == x || xs > x) break;
-            ++j;
+    // chunks of 4 target levels: the next chunk's loads are in flight while this one is interpolated
+    constexpr int U = 4;
+    double nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)(u < N ? u : N - 1) * ncol];
+    for (int l0 = 0; l0 < N; l0 += U) {
+        double cx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cx[u] = nx[u];
+        if (l0 + U < N) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol];
         }
-        bool extrap;
-        double y = interp_pick<MODE>(j, S, x, sx, sy, TPB, extrap);
-        if (MODE == 0 && extrap) report(st, 12, flat);           // :564-566
-        po[(long long)l * ncol] = (T)y;
-        xprev = (x == x) ? x : __builtin_inf();                  // after a NaN target restart
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u;
+            if (l < N) {
+                double x = cx[u];
+                if (!logp_in) x = pgw_log(x);                            // :471
+                if (!(x >= xprev)) j = 0;                                // restart (descending or NaN)
+                while (j < S) {
+                    double xs = sx[j * TPB];
+                    if (xs == x || xs > x) break;
+                    ++j;
+                }
+                bool extrap;
+                double y = interp_pick<MODE>(j, S, x, sx, sy, TPB, extrap);
+                if (MODE == 0 && extrap) report(st, 12, flat);           // :564-566
+                po[(long long)l * ncol] = (T)y;
+                xprev = (x == x) ? x : __builtin_inf();                  // after a NaN target restart
+            }
+        }
     }
 }
 
