@@ -194,7 +194,22 @@ int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol,
                        const double *phi_ref_era, const double *dphi_clim,
                        double *delta_ps, double *adj_ps,
                        double p_ref, const double *p_ref_field, double adj_factor,
-                       double *max_abs_err);
+                       int apply_adj, double *max_abs_err);
+/* apply_adj != 0: the pass itself does delta_ps += adj_ps (step_03:192); 0: the caller already did
+ * (pgw_update_ps), as needed when the model-level pressures of the pass are required beforehand
+ * (i_reinterp = 1, step_03:202-216). */
+
+/* step_03:192-193: delta_ps += adj_ps ; ps_pgw = PS + delta_ps.  PS, ps_pgw storage dtype (ntime,ncol);
+ * delta_ps, adj_ps double. */
+int pgw_update_ps(pgw_ctx *ctx, int dtype, long long n, const void *PS, double *delta_ps,
+                  const double *adj_ps, void *ps_pgw);
+
+/* phi_ref of a hybrid-level state (T, QV, PS, FIS) at scalar or per-column p_ref, fp64 output:
+ * integ_geopot(ak + PS*bk, FIS, T, QV, ., p_ref) without the 4-D pressure array
+ * (step_03:280-287 with :64-66). */
+int pgw_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *T, const void *QV,
+                       const void *PS, const void *FIS, double p_ref, const double *p_ref_field,
+                       double *phi_ref);
 
 /* a5 the whole loop step_03_apply_to_era.py:182-319 with its control flow: passes until
  * max|err| <= thresh; error when the pass counter exceeds max_n_iter (so at most

@@ -684,6 +684,51 @@ def _zonal_mean(row):
 # ----------------------------------------------------------------------------------------
 # whole-file restatement on arrays                                   step_03:44-381
 # ----------------------------------------------------------------------------------------
+def pgw_for_era5_arrays_reinterp(era, deltas, delta_times, plev, target_dt,
+                                 ignore_top_pressure_error=False, p_ref=P_REF_INP):
+    """pgw_for_era5 with i_reinterp = 1 (step_03:202-216, 330-343) and fixed p_ref."""
+    ak, bk = era['ak'], era['bk']
+    akm, bkm = era.get('akm'), era.get('bkm')
+    if akm is None:
+        akm, bkm = full_level_coeffs(ak, bk)
+    f64 = lambda x: np.asarray(x, dtype=np.float64)
+    PS, T, QV, FIS = f64(era['PS']), f64(era['T']), f64(era['QV']), f64(era['FIS'])
+    pa_hl_era, pa_era = hybrid_pressure(ak, bk, PS, akm, bkm)
+    relhum = specific_to_relative_humidity(QV, pa_era, T)
+    ld = lambda name: load_delta_values(deltas[name], delta_times, target_dt)
+    level1 = np.arange(1, len(ak) + 1)
+    plev = np.asarray(plev, dtype=np.float64)
+    kref = int(np.nonzero(plev == p_ref)[0][0])
+    dzg = ld('zg')[:, kref]
+    era_fields = dict(ta=T, hur=relhum, ua=f64(era['U']), va=f64(era['V']))
+
+    def reinterp(var, pa_pgw):
+        e = interp_logp_4d(era_fields[var], pa_era, pa_pgw, extrapolate='constant')         # :209-211
+        dsfc, psh = (ld(var + 's'), ld('ps_hist')) if var in ('ta', 'hur') else (None, None)
+        return e + vert_interp_delta(ld(var), plev, pa_pgw, dsfc, psh, ignore_top_pressure_error)   # :212-216
+
+    delta_ps = np.zeros_like(PS); adj_ps = np.zeros_like(PS)
+    err_max = np.inf
+    it = 1
+    hist = []
+    phi_ref_era = integ_geopot(pa_hl_era, FIS, T, QV, level1, p_ref)
+    while err_max > THRESH_PHI_REF_MAX_ERROR:
+        delta_ps = delta_ps + adj_ps
+        ps_pgw = PS + delta_ps
+        pa_hl_pgw, pa_pgw = hybrid_pressure(ak, bk, ps_pgw, akm, bkm)
+        ta_pgw, hur_pgw = reinterp('ta', pa_pgw), reinterp('hur', pa_pgw)
+        hus_pgw = relative_to_specific_humidity(hur_pgw, pa_pgw, ta_pgw)
+        err = (integ_geopot(pa_hl_pgw, FIS, ta_pgw, hus_pgw, level1, p_ref) - phi_ref_era) - dzg * CON_G
+        adj_ps = - ADJ_FACTOR * ps_pgw / (CON_RD * ta_pgw[:, -1]) * err
+        err_max = np.nanmax(np.abs(err))
+        hist.append(float(err_max))
+        it += 1
+        if it > MAX_N_ITER:
+            raise ValueError('ERROR! Pressure adjustment did not converge')
+    return dict(PS=ps_pgw, T=ta_pgw, QV=hus_pgw, U=reinterp('ua', pa_pgw), V=reinterp('va', pa_pgw),
+                RELHUM_pgw=hur_pgw, n_iter=it - 1, max_err=hist)
+
+
 def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt,
                         ignore_top_pressure_error=False, p_ref=P_REF_INP):
     """pgw_for_era5 (step_03:44-381) with i_reinterp = 0 and fixed p_ref on in-memory arrays.

@@ -73,7 +73,9 @@ SIGNATURES = {
                                    _vp, _vp, _i, _vp, _vp]),
     'pgw_replace_delta_sfc': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _vp, _vp, _vp]),
     'pgw_integrate_tos': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp]),
-    'pgw_adjust_ps_step': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _dp]),
+    'pgw_adjust_ps_step': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _i, _dp]),
+    'pgw_update_ps': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp]),
+    'pgw_phi_ref_hybrid': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _d, _vp, _vp]),
     'pgw_adjust_ps_loop': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _d, _i,
                                 _vp, _vp, _ip, _dp]),
     'pgw_last_levels_touched': (C.c_ulonglong, [_vp]),

@@ -742,7 +742,7 @@ static int full_column_env() {
 extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta_pgw,
                                   const void *hur_pgw, const void *PS, const void *FIS, const double *phi_ref_era,
                                   const double *dphi_clim, double *delta_ps, double *adj_ps, double p_ref,
-                                  const double *p_ref_field, double adj_factor, double *max_abs_err) {
+                                  const double *p_ref_field, double adj_factor, int apply_adj, double *max_abs_err) {
     CHECK_COMMON(ctx, dtype, ntime, ncol);
     NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
     NEED(ctx, ta_pgw && hur_pgw && PS && FIS && phi_ref_era && dphi_clim && delta_ps && adj_ps, "null pointer");
@@ -755,11 +755,34 @@ extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long 
     rc = status_reset(ctx);
     if (rc) return rc;
     launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref,
-                p_ref_field, adj_factor, full_column_env());
+                p_ref_field, adj_factor, full_column_env(), apply_adj ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     rc = status_check(ctx);
     if (max_abs_err) *max_abs_err = max_err_of(ctx);
     return rc;
+}
+
+extern "C" int pgw_update_ps(pgw_ctx *ctx, int dtype, long long n, const void *PS, double *delta_ps,
+                             const double *adj_ps, void *ps_pgw) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, n >= 1 && PS && delta_ps && adj_ps && ps_pgw, "bad argument");
+    DISPATCH_T(dtype, hipLaunchKernelGGL((k_update_ps<T>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, n,
+                                         (const T *)PS, delta_ps, adj_ps, (T *)ps_pgw));
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+extern "C" int pgw_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *T, const void *QV,
+                                  const void *PS, const void *FIS, double p_ref, const double *p_ref_field,
+                                  double *phi_ref) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, T && QV && PS && FIS && phi_ref, "null pointer");
+    int rc = status_reset(ctx);
+    if (rc) return rc;
+    launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_ref, full_column_env(), p_ref_field);
+    HIPCHK(ctx, hipGetLastError());
+    return status_check(ctx);
 }
 
 // The loop of step_03_apply_to_era.py:182-319 given the iterate-independent vapour pressure

@@ -1192,6 +1192,17 @@ __global__ __launch_bounds__(BLOCK) void k_local_p_ref(PlevTable pt /* p[] in FI
     dphi[i] = zg.get((t * pt.n + k) * ncol + c) * CON_G;            // step_03:292-295
 }
 
+// step_03:192-193
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_update_ps(long long n, const T *__restrict__ PS, double *__restrict__ delta_ps,
+                                                     const double *__restrict__ adj_ps, T *__restrict__ ps_out) {
+    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double d = delta_ps[i] + adj_ps[i];
+    delta_ps[i] = d;
+    ps_out[i] = (T)((double)PS[i] + d);
+}
+
 // g * time-interpolated zg delta at p_ref -> fp64 loop constant (step_03:292-295)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z, double g, double *__restrict__ out) {

@@ -209,8 +209,106 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     return out, info
 
 
+def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error=False,
+                                 p_ref=None, out=None):
+    """settings.i_reinterp = 1 (reference step_03:202-216, 330-343): in every pass the ERA ta / hur
+    fields and their deltas are re-interpolated onto the CURRENT model-level pressures, ua / va once
+    after convergence.  Composed from the function-level C-ABI entries (pressure_levels,
+    interp_logp_4d 'constant', vert_interp_delta, adjust_ps_step); the loop control is the reference's.
+    Same inputs / outputs as process_file_device (fixed p_ref only)."""
+    lib, h = ctx.lib, ctx.handle
+    p_ref = S.p_ref_inp if p_ref is None else p_ref
+    if p_ref is None or p_ref == 'local':
+        raise NotImplementedError('i_reinterp = 1 together with p_ref_inp = None is not built')
+    dt = deltas.dtype
+    tag = dtype_tag(dt)
+    ctx.set_levels(coeffs['ak'], coeffs['bk'], coeffs.get('akm'), coeffs.get('bkm'))
+    T, QV, PS, FIS = era['T'], era['QV'], era['PS'], era['FIS']
+    nt, N, nlat, nlon = T.shape
+    ncol, n2 = nlat * nlon, nt * nlat * nlon
+    out = {} if out is None else out
+    f64 = np.dtype('float64')
+
+    def buf(name, shape, dtype=dt):
+        if name not in out or out[name].shape != tuple(shape) or out[name].dtype != dtype:
+            out[name] = ctx.empty(shape, dtype)
+        return out[name]
+
+    ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)
+    rb, ra = int(keep[ib]), int(keep[ia])
+    plev = deltas.plev
+    dev = deltas.dev
+    kref = np.nonzero(plev == p_ref)[0]
+    if len(kref) != 1:
+        raise KeyError(p_ref)
+    # ERA state: pa_era (4-D, needed as source axis), RELHUM (step_03:87-94), phi_ref_era, g*dzg
+    pa_era = buf('_pa_era', T.shape)
+    ctx._check(lib.pgw_pressure_levels(h, tag, nt, ncol, PS.ptr, None, pa_era.ptr))
+    relhum = buf('_RELHUM', T.shape)
+    ctx._check(lib.pgw_specific_to_relative_humidity_hybrid(h, tag, nt, ncol, QV.ptr, PS.ptr, T.ptr, relhum.ptr))
+    phi_era = buf('_phi_era', PS.shape, f64)
+    ctx._check(lib.pgw_phi_ref_hybrid(h, tag, nt, ncol, T.ptr, QV.ptr, PS.ptr, FIS.ptr, float(p_ref), None, phi_era.ptr))
+    dzg = buf('_dzg', PS.shape)
+    zb, za = dev['zg'].slab(rb).slab(int(kref[0])), dev['zg'].slab(ra).slab(int(kref[0]))
+    if x_hi == 0.0:
+        ctx._check(lib.pgw_memcpy_d2d(h, dzg.ptr, zb.ptr, zb.nbytes))
+    else:
+        ctx._check(lib.pgw_time_lerp(h, tag, zb.size, zb.ptr, za.ptr, x_hi, x_new, dzg.ptr))
+    dphi = ctx.to_device(dzg.numpy().astype(np.float64) * CON_G, f64)          # step_03:292-293 (2-D, once)
+    delta_ps, adj_ps = ctx.zeros(PS.shape, f64), ctx.zeros(PS.shape, f64)        # :182-184
+    ps_pgw, pa_pgw = buf('PS', PS.shape), buf('_pa_pgw', T.shape)
+    tmp = buf('_tmp', T.shape)
+
+    def reinterp(var, era_field, target):
+        """interp_logp_4d(era, pa_era, pa_pgw, 'constant') + load_delta_interp(var, pa_pgw)  :209-216"""
+        ctx._check(lib.pgw_interp_logp_4d(h, tag, nt, N, N, ncol, era_field.ptr, pa_era.ptr, pa_pgw.ptr, 2, 0, tmp.ptr))
+        if var in ('ta', 'hur'):
+            sfc, psh = dev[var + 's'], dev['ps_hist']
+            sb, sa, pb, pa_ = sfc.slab(rb).ptr, sfc.slab(ra).ptr, psh.slab(rb).ptr, psh.slab(ra).ptr
+        else:
+            sb = sa = pb = pa_ = None
+        ctx._check(lib.pgw_vert_interp_delta(h, tag, nt, len(plev), N, ncol, plev.ctypes.data_as(_dp),
+                                             dev[var].slab(rb).ptr, dev[var].slab(ra).ptr, x_hi, x_new, sb, sa, pb, pa_,
+                                             pa_pgw.ptr, None, 1 if ignore_top_pressure_error else 0, tmp.ptr, target.ptr))
+
+    ta_pgw, hur_pgw = buf('T', T.shape), buf('_hur_pgw', T.shape)
+    err = np.inf
+    it = 1
+    hist = []
+    max_err = C.c_double()
+    while err > S.thresh_phi_ref_max_error:                                       # :189
+        ctx._check(lib.pgw_update_ps(h, tag, n2, PS.ptr, delta_ps.ptr, adj_ps.ptr, ps_pgw.ptr))   # :192-193
+        ctx._check(lib.pgw_pressure_levels(h, tag, nt, ncol, ps_pgw.ptr, None, pa_pgw.ptr))        # :196-197
+        reinterp('ta', T, ta_pgw)
+        reinterp('hur', relhum, hur_pgw)
+        ctx._check(lib.pgw_adjust_ps_step(h, tag, nt, ncol, ta_pgw.ptr, hur_pgw.ptr, PS.ptr, FIS.ptr, phi_era.ptr,
+                                          dphi.ptr, delta_ps.ptr, adj_ps.ptr, float(p_ref), None, float(S.adj_factor), 0,
+                                          C.byref(max_err)))
+        err = max_err.value                                                       # :308
+        hist.append(err)
+        it += 1
+        if it > S.max_n_iter:                                                     # :313-319
+            raise ValueError('ERROR! Pressure adjustment did not converge')
+    reinterp('ua', era['U'], buf('U', T.shape))                                   # :330-343
+    reinterp('va', era['V'], buf('V', T.shape))
+    ctx._check(lib.pgw_relative_to_specific_humidity_hybrid(h, tag, nt, ncol, hur_pgw.ptr, ps_pgw.ptr, ta_pgw.ptr,
+                                                            buf('QV', T.shape).ptr))   # hus of the last pass, :262-266,370
+    if 'FR_SEA_ICE' in era and 'siconc' in dev:                                   # surface riders :103-146
+        s3 = era['T_SKIN'].shape
+        soil = np.ascontiguousarray(coeffs['soil1'], dtype=np.float64)
+        ctx._check(lib.pgw_surface_update(
+            h, tag, nt, ncol, len(soil), soil.ctypes.data_as(_dp), era['FR_SEA_ICE'].ptr,
+            deltas.lerp2d('siconc', target_dt, buf('_dsic', s3)).ptr, deltas.lerp2d('tos', target_dt, buf('_dtos', s3)).ptr,
+            deltas.lerp2d('ts', target_dt, buf('_dts', s3)).ptr, era['FR_LAND'].ptr, deltas.ts_clim.ptr,
+            era['T_SKIN'].ptr, era['T_SO'].ptr, buf('FR_SEA_ICE', s3).ptr, buf('_dts_comb', s3).ptr,
+            buf('T_SKIN', s3).ptr, buf('T_SO', era['T_SO'].shape).ptr))
+    for x in (dphi, delta_ps, adj_ps):
+        x.free()
+    return out, dict(n_iter=it - 1, max_err=hist, levels_touched=0)
+
+
 def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, dtype=None):
+                        p_ref=None, dtype=None, i_reinterp=False):
     """Whole-file path on in-memory host arrays (upload, compute on the GPU, download)."""
     ctx = default_context()
     if dtype is None:
@@ -219,7 +317,10 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     ds = DeltaSet(ctx, deltas, delta_times, plev, dtype)
     e = _upload_era(ctx, era, dtype)
     coeffs = dict(ak=era['ak'], bk=era['bk'], akm=era.get('akm'), bkm=era.get('bkm'), soil1=era['soil1'])
-    out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref, keep_hur=True)
+    if i_reinterp:
+        out, info = process_file_device_reinterp(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref)
+    else:
+        out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref, keep_hur=True)
     res = {k: v.numpy() for k, v in out.items() if not k.startswith('_')}
     res['RELHUM_pgw'] = out['_hur_pgw'].numpy()
     res.update(info)
@@ -268,8 +369,6 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
     if debug_mode is not None:
         raise NotImplementedError('debug_mode (step_03_apply_to_era.py:350-361, 387-414) is a validation aid of '
                                   'the reference and not part of the MI355X hot path')
-    if S.i_reinterp:
-        raise NotImplementedError('i_reinterp = 1 is not built yet (SURVEY.md section 8 f)')
     if S.i_debug >= 0:
         print('Start working on input file {}'.format(inp_era_file_path))
     era_file = ncio.open_dataset(inp_era_file_path, decode_times=False)      # step_03:60
@@ -310,8 +409,9 @@ def _stage_compute(item):
         if k not in bufs['inp']:
             bufs['inp'][k] = ctx.empty(v.shape, dtype)
         bufs['inp'][k].copy_from(v)
-    out, info = process_file_device(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
-                                    p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
+    run = process_file_device_reinterp if S.i_reinterp else process_file_device
+    out, info = run(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
+                    p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
     item['result'] = {k: out[k].numpy() for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE')}
     item['info'] = info
     item['era'] = None                                  # release the host copies of the inputs

@@ -481,3 +481,23 @@ def test_local_p_ref_no_candidate_error():
     with pytest.raises(ValueError) as e:
         s3.pgw_for_era5_arrays(c['era'], d, c['delta_times'], c['plev'][keep], c['target_dt'], True, p_ref='local')
     assert 'No reference pressure level' in str(e.value)
+
+
+# ------------------------------------------------------------------ i_reinterp = 1 (SURVEY 8 f, rank 3)
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_reinterp_mode_vs_oracle(dtype):
+    """settings.i_reinterp = 1: ERA fields and deltas re-interpolated onto the updated model levels in
+    every pass, ua / va after convergence (reference step_03_apply_to_era.py:202-216, 330-343)."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c = _case(8, 10, 24, seed=31, dtype=dtype)
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, i_reinterp=True)
+    want = O.pgw_for_era5_arrays_reinterp(c['era'], {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()},
+                                          c['delta_times'], c['plev'], c['target_dt'], True)
+    assert got['n_iter'] == want['n_iter']
+    tol = 1e-9 if dtype == np.float64 else 2e-6
+    for k in ['PS', 'T', 'U', 'V']:
+        np.testing.assert_allclose(got[k], want[k], rtol=tol, atol=1e-5 if dtype == np.float32 else 1e-9, err_msg=k)
+    np.testing.assert_allclose(got['QV'], want['QV'], rtol=tol if dtype == np.float64 else 5e-6, atol=1e-18)
+    # differs from the default mode (deltas interpolated once on the ERA levels)
+    base = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    assert np.abs(base['T'] - got['T']).max() > 1e-6
