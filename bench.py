@@ -383,8 +383,9 @@ def pmc_traffic(kernel, a):
         return None, None
     d = json.load(open(files[-1]))
     pat = PMC_KERNEL.get(kernel, '?')
-    if 'k_delta_pair' in pat:
-        match = lambda k: k.startswith('k_delta_pair') and k.endswith(pat.split(', ')[-1])
+    if 'k_delta_pair' in pat:           # k_delta_pair<T, V, THERMO, U, TPB, STAGED>: the third argument tells the pair
+        want = 'true' if kernel == 'thermo_delta' else 'false'
+        match = lambda k: k.startswith('k_delta_pair<') and k[len('k_delta_pair<'):].split(', ')[2] == want
     else:
         match = lambda k: k.startswith(pat)
     vals = [v['hbm_bytes_per_launch'] for k, v in d.items() if match(k) and 'hbm_bytes_per_launch' in v]

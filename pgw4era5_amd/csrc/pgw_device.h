@@ -27,6 +27,19 @@ struct DevStatus {
     unsigned long long levels_touched; // sum over columns of levels read (early-exit kernels)
 };
 
+// Device-resident control block of the surface-pressure loop (step_03:182-319) when the passes are
+// enqueued back to back without a host round trip: every pass kernel returns at once if `done`
+// is set; the block that arrives last publishes the pass's max|err|, decides `done` with the
+// reference's test (NOT err > thresh, so NaN stops the loop too) and re-arms the accumulators.
+struct LoopState {
+    int done;                          // 1 once a pass ended with max|err| <= thresh
+    int n_iter;                        // passes executed
+    unsigned int arrivals;             // blocks of the current pass that have reported
+    int pad;
+    double max_err[32];
+    unsigned long long levels[32];     // levels read per pass (bytes-moved accounting)
+};
+
 template <typename T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
 
 template <typename T, int V>

@@ -340,10 +340,13 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
                                                           double *__restrict__ delta_ps, double *__restrict__ adj_ps,
                                                           double p_ref_s, const double *__restrict__ p_ref_f,
                                                           double adj_factor, int full_column, int apply_adj,
-                                                          DevStatus *st) {
+                                                          DevStatus *st, LoopState *ls, double thresh) {
     __shared__ double s_max[BLOCK / 64];
     __shared__ unsigned int s_valid[BLOCK / 64];
     __shared__ double s_lev[LEVTAB_DOUBLES];
+    // device-controlled loop: a pass enqueued after convergence is a no-op (the flag was written by
+    // an earlier kernel on this stream, so the kernel boundary makes it visible)
+    if (ls && ls->done) return;
     LevTab lt = stage_levels<true, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
@@ -398,6 +401,28 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
             atomicAdd(&st->valid, 1ull);
         }
         atomicAdd(&st->levels_touched, tch);
+        if (ls) {
+            // last-arriver: agent-scope atomics above, fence, then the arrival ticket; the block that draws
+            // the last ticket reads the accumulators with atomic RMWs (coherent across XCDs)
+            __threadfence();
+            unsigned int ticket = atomicAdd(&ls->arrivals, 1u);
+            if (ticket == gridDim.x - 1) {
+                __threadfence();
+                unsigned long long bits = atomicMax(&st->max_bits, 0ull);
+                unsigned long long nvalid = atomicAdd(&st->valid, 0ull);
+                unsigned long long lev = atomicAdd(&st->levels_touched, 0ull);
+                double mx = nvalid ? __longlong_as_double((long long)bits) : __builtin_nan("");   // xarray .max() of all-NaN
+                int it = ls->n_iter;
+                if (it < 32) { ls->max_err[it] = mx; ls->levels[it] = lev; }
+                ls->n_iter = it + 1;
+                if (!(mx > thresh)) ls->done = 1;                         // step_03:189
+                atomicExch(&st->max_bits, 0ull);                          // re-arm for the next pass
+                atomicExch(&st->valid, 0ull);
+                atomicExch(&st->levels_touched, 0ull);
+                atomicExch(&ls->arrivals, 0u);
+                __threadfence();
+            }
+        }
     }
 }
 

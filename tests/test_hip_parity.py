@@ -501,3 +501,21 @@ def test_reinterp_mode_vs_oracle(dtype):
     # differs from the default mode (deltas interpolated once on the ERA levels)
     base = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
     assert np.abs(base['T'] - got['T']).max() > 1e-6
+
+
+def test_device_controlled_loop_matches_host_controlled(monkeypatch):
+    """PGW_DEVICE_LOOP=1 (passes enqueued back to back, `done` flag and max|err| kept on the device)
+    gives bit-identical results and the same iteration count as the host-controlled loop."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c = _case(9, 16, 30, seed=41)
+    a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    monkeypatch.setenv('PGW_DEVICE_LOOP', '1')
+    b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
+    for k in ['PS', 'T', 'QV', 'U', 'V']:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    import pgw4era5_amd.settings as S
+    monkeypatch.setattr(S, 'max_n_iter', 3)
+    with pytest.raises(ValueError) as e:
+        s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    assert 'did not converge' in str(e.value)
