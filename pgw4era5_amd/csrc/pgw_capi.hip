@@ -37,6 +37,7 @@ struct pgw_ctx {
     // profiler
     bool prof_on = false;
     std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> event_pool;      // recycled profiling events (create/destroy per launch is slow)
     long long prof_count[PGW_K_COUNT];
     double prof_ms[PGW_K_COUNT];
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -94,9 +95,15 @@ static const char *status_text(int code) {
 // ------------------------------------------------------------------ launch helpers
 struct Prof {
     pgw_ctx *c; int kid; hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t take() {
+        hipEvent_t e = nullptr;
+        if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+        else hipEventCreate(&e);
+        return e;
+    }
     Prof(pgw_ctx *c_, int kid_) : c(c_), kid(kid_) {
         if (c->prof_on) {
-            hipEventCreate(&e0); hipEventCreate(&e1);
+            e0 = take(); e1 = take();
             hipEventRecord(e0, c->stream);
         }
     }
@@ -116,7 +123,7 @@ static int prof_resolve(pgw_ctx *ctx) {
         hipEventElapsedTime(&ms, r.e0, r.e1);
         ctx->prof_count[r.kid] += 1;
         ctx->prof_ms[r.kid] += ms;
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        ctx->event_pool.push_back(r.e0); ctx->event_pool.push_back(r.e1);
     }
     ctx->prof_pending.clear();
     return PGW_OK;
@@ -226,6 +233,7 @@ extern "C" int pgw_ctx_destroy(pgw_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &r : ctx->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    for (auto &e : ctx->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 8; ++i) if (ctx->ws[i]) hipFree(ctx->ws[i]);
     if (ctx->d_levels) hipFree(ctx->d_levels);
     if (ctx->d_small) hipFree(ctx->d_small);
