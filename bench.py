@@ -179,6 +179,9 @@ def main():
                     frac=round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_unit='GB/launch',
                     traffic_source=tsrc, avg_launch_ms=kern[dom]['avg_ms'],
                     algorithmic_GB_per_launch=kern[dom]['algo_GB'])
+        valu = pmc_valu(dom, a, kern[dom]['avg_ms'])
+        if valu:
+            roof['valu_fp64'] = valu
         files = a.steps * world
         res = {
             'metric': 'ERA5 files/hour (0.25deg L137), step_03 hot path, inputs resident in HBM',
@@ -397,6 +400,35 @@ def pmc_traffic(kernel, a):
     if not vals:
         return None, None
     return round(sum(vals) / len(vals) / 1e9, 4), os.path.relpath(files[-1], ROOT)
+
+
+FP64_VALU_PEAK_LANE_OPS = 78.6e12 / 2          # MI355X: 78.6 TFLOP/s fp64 vector = 39.3e12 FMA lanes / s
+
+
+def pmc_valu(kernel, a, avg_ms):
+    """For kernels that are bound by fp64 vector issue rather than HBM (the ta+hur pair kernel: one log,
+    2-4 exp and 7 IEEE divisions per level and column): VALU wave-instructions per launch from the committed
+    SQ PMC pass x 64 lanes / launch time, against the fp64 FMA issue peak."""
+    import glob
+    if (a.nlat, a.nlon, a.nlev) != (721, 1440, 137):
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_summary_*_%s.json' % a.storage)))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    want = 'true' if kernel == 'thermo_delta' else 'false'
+    pat = PMC_KERNEL.get(kernel, '?')
+    for k, v in d.items():
+        ok = (k.startswith('k_delta_pair<') and k[len('k_delta_pair<'):].split(', ')[2] == want) if 'k_delta_pair' in pat \
+            else k.startswith(pat)
+        if ok and 'SQ_INSTS_VALU' in v:
+            rate = v['SQ_INSTS_VALU'] * 64 / (avg_ms / 1e3)
+            return {'valu_wave_insts_per_launch': round(v['SQ_INSTS_VALU']), 'lane_ops_per_s': round(rate / 1e12, 2),
+                    'unit': 'T lane-ops/s', 'peak': FP64_VALU_PEAK_LANE_OPS / 1e12,
+                    'frac_of_fp64_issue_peak': round(rate / FP64_VALU_PEAK_LANE_OPS, 3),
+                    'valu_active_share_of_wave_time': round(v.get('valu_active_share_of_wave_time', 0), 3),
+                    'source': os.path.relpath(files[-1], ROOT)}
+    return None
 
 
 def cpu_baseline(case, a, np):

@@ -2,7 +2,7 @@
 """Condense rocprofv3 output directories (under gpurun_out/) into the small tracked summaries
 in profiles/.
 
-    python profiles/summarize.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+    python profiles/summarize.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir> [<pmc_sq_dir>]]
 
 stats_dir: output of  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py ...
 pmc dirs : output of  rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d <dir> -- python3 bench.py ...
@@ -53,6 +53,25 @@ def main():
         for k, v in out.items():
             if 'FETCH_SIZE_KiB' in v and 'WRITE_SIZE_KiB' in v:
                 v['hbm_bytes_per_launch'] = (2 * v['FETCH_SIZE_KiB'] + v['WRITE_SIZE_KiB']) * 1024
+    if len(sys.argv) >= 6:
+        # SQ pass (rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY ...):
+        # wave-instructions per launch; SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles (x4 = cycles)
+        f = glob.glob(os.path.join(sys.argv[5], '**', '*_counter_collection.csv'), recursive=True)[0]
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        for k, v in agg.items():
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            d = out.setdefault(k, {})
+            for c in ('SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU'):
+                if c in m:
+                    d[c] = m[c]
+            if 'SQ_WAVE_CYCLES' in m and m['SQ_WAVE_CYCLES'] > 0:
+                for c, name in (('SQ_ACTIVE_INST_VALU', 'valu_active_share_of_wave_time'),
+                                ('SQ_WAIT_INST_ANY', 'issue_stall_share_of_wave_time'),
+                                ('SQ_WAIT_ANY', 'waitcnt_share_of_wave_time')):
+                    if c in m:
+                        d[name] = m[c] / m['SQ_WAVE_CYCLES']
     with open(os.path.join(here, 'pmc_summary_%s.json' % tag), 'w') as o:
         json.dump(out, o, indent=1, sort_keys=True)
     for k, v in sorted(out.items()):
