@@ -125,7 +125,7 @@ def load():
             '`make -C pgw4era5_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`. '
             'pgw4era5_amd has no CPU fallback.' % LIB_PATH)
     try:
-        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if 'torch' not in sys.modules else C.RTLD_LOCAL)
+        lib = C.CDLL(LIB_PATH)
     except OSError as e:
         raise ImportError('cannot load %s: %s (is the ROCm runtime libamdhip64.so.7 on the '
                           'library path?)' % (LIB_PATH, e))

@@ -491,19 +491,6 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
     }
 }
 
-// g * dzg (step_03:292-293) into the fp64 state array
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_scale_to_f64(long long n, const T *__restrict__ x, double s,
-                                                        double *__restrict__ out) {
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = (double)x[i] * s;
-}
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_to_f64(long long n, const T *__restrict__ x, double *__restrict__ out) {
-    long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = (double)x[i];
-}
-
 // =====================================================================================
 // a6  interp_logp_4d, signature-faithful                       functions.py:434-580
 // Source columns (ln p and values) are staged once in LDS, laid out [level][thread] so a
