@@ -97,6 +97,12 @@ def test_step02_cli_regridding(tmp_path):
         ds['lat'] = F(g['src_lat'], ('lat',)); ds['lon'] = F(g['src_lon'], ('lon',))
         ds['ta'] = F(g['field'], ('time', 'plev', 'lat', 'lon'), attrs=dict(units='K'))
         ncio.to_netcdf(ds, str(inp / base))
+    for base in ('tas_delta.nc', 'tas_historical.nc'):           # a 3-D (time, lat, lon) variable, descending-free
+        ds = ncio.Dataset()
+        ds['time'] = F(times, ('time',))
+        ds['lat'] = F(g['src_lat'], ('lat',)); ds['lon'] = F(g['src_lon'], ('lon',))
+        ds['tas'] = F(g['field'][:, 0].astype(np.float32), ('time', 'lat', 'lon'))
+        ncio.to_netcdf(ds, str(inp / base))
     era = ncio.Dataset()
     era['lat'] = F(g['targ_lat'], ('lat',)); era['lon'] = F(g['targ_lon'], ('lon',))
     era['FR_LAND'] = F(np.zeros((1, 19, 36)), ('time', 'lat', 'lon'))
@@ -110,6 +116,11 @@ def test_step02_cli_regridding(tmp_path):
     np.testing.assert_array_equal(res['lat'].values, g['targ_lat'])
     np.testing.assert_array_equal(res['plev'].values, plev)
     assert res['ta'].attrs['units'] == 'K'
+    done = s2.main(['regridding', '-i', str(inp), '-o', str(out), '-e', str(tmp_path / 'era.nc'), '-v', 'tas'])
+    res = ncio.open_dataset(str(out / 'tas_historical.nc'))
+    assert res['tas'].dims == ('time', 'lat', 'lon') and res['tas'].dtype == np.float32
+    want = O.regrid_lat_lon(g['field'][:, 0].astype(np.float32), g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon'])
+    np.testing.assert_allclose(res['tas'].values, want, rtol=1e-6, atol=1e-6)
     with pytest.raises(NotImplementedError):
         s2.main(['regridding', '-i', str(inp), '-o', str(out), '-e', str(tmp_path / 'era.nc'), '-v', 'tos'])
 

@@ -519,3 +519,64 @@ def test_device_controlled_loop_matches_host_controlled(monkeypatch):
     with pytest.raises(ValueError) as e:
         s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
     assert 'did not converge' in str(e.value)
+
+
+# ------------------------------------------------------------------ ragged / odd shapes, other level sets
+@pytest.mark.parametrize('shape', [(7, 13, 21), (3, 5, 9), (1, 3, 6), (2, 2, 5)])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_whole_file_odd_shapes(shape, dtype):
+    """Column counts that are not multiples of the vector width (scalar-column code path), level counts
+    that are not multiples of the prefetch chunk, single rows / tiny grids."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    nlat, nlon, nlev = shape
+    c = _case(nlat, nlon, nlev, seed=50 + nlat * nlon, dtype=dtype)
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    era64 = {k: (np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
+             for k, v in c['era'].items()}
+    want = O.pgw_for_era5_arrays(era64, {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()},
+                                 c['delta_times'], c['plev'], c['target_dt'], True)
+    assert got['n_iter'] == want['n_iter']
+    tol = 1e-9 if dtype == np.float64 else 1e-6
+    for k in ['PS', 'T', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+        np.testing.assert_allclose(got[k], want[k], rtol=tol, atol=1e-5 if (dtype == np.float32 and k in 'UV') else 1e-12,
+                                   equal_nan=True, err_msg=k)
+    np.testing.assert_allclose(got['QV'], want['QV'], rtol=tol if dtype == np.float64 else 3e-6, atol=1e-18)
+
+
+def test_whole_file_plev34_and_exact_month():
+    """34 delta levels (the Emon+Amon merge of step_01, Emon_add_top_from_Amon.sh:45,50) and a time stamp
+    that hits a delta record exactly (no lerp, functions.py:282-283)."""
+    import datetime as dt
+    from pgw4era5_amd import step_03_apply_to_era as s3, synthetic
+    plev34 = np.concatenate([np.array([100000., 97500, 95000, 92500, 90000, 87500, 85000, 82500, 80000, 77500, 75000,
+                                       70000, 65000, 60000, 55000, 50000, 45000, 40000, 35000, 30000, 25000, 22500,
+                                       20000, 17500, 15000, 12500, 10000]), synthetic.PLEV19[12:]])
+    assert len(plev34) == 34
+    c = synthetic.make_case(6, 10, 40, seed=61, plev=plev34, target_dt=dt.datetime(2006, 3, 15, 12))
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    want = O.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    assert got['n_iter'] == want['n_iter']
+    for k in ['PS', 'T', 'QV', 'U', 'V']:
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-12, err_msg=k)
+
+
+def test_whole_file_errors_reach_python():
+    """Data errors inside the fused file path surface as the reference's exceptions."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c = _case(5, 6, 16, seed=71)
+    with pytest.raises(ValueError) as e:                          # model top above delta top, no -t
+        s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], False)
+    assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
+    bad = {k: v.copy() for k, v in c['deltas'].items()}
+    bad['ps_hist'][:, 2, 3] = 50.0                                # HIST surface pressure above the delta top
+    with pytest.raises(ValueError) as e:
+        s3.pgw_for_era5_arrays(c['era'], bad, c['delta_times'], c['plev'], c['target_dt'], True)
+    assert str(e.value) == '' and e.value.column == 2 * 6 + 3
+    with pytest.raises(ValueError) as e:                          # p_ref below the surface somewhere
+        s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref=100000.0)
+    assert 'p_ref locally lies below the surface' in str(e.value)
+    with pytest.raises(KeyError):                                 # .sel(plev=p_ref) with a level that is not in the file
+        s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref=31000.0)
+    era = dict(c['era']); era['PS'] = c['era']['PS'].copy(); era['PS'][0, 1, 1] = np.nan
+    with pytest.raises(ValueError):                               # NaN surface pressure: all-NaN p_diff column
+        s3.pgw_for_era5_arrays(era, c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
