@@ -60,6 +60,8 @@ def kernel_bytes(name, N, S, ncol, s, info):
     if name == 'adjust_ps_step':      # ta, e per level read; PS,FIS (storage) + 6 fp64 state words
         lv = info.get('levels_per_launch', N * ncol)
         return 2 * lv * s + ncol * (2 * s + 6 * 8)
+    if name == 'quad_delta':          # T, QV, U, V in; T_pgw, e, U_pgw, V_pgw out; 2 records x S for 4 variables; 8 2-D fields
+        return (8 * N + 8 * S + 8) * ncol * s
     if name == 'thermo_delta':        # T, QV in; T_pgw, e out; 2 records x S for ta and hur; 7 2-D fields
         return (4 * N + 4 * S + 7) * ncol * s
     if name == 'wind_delta':          # U, V in; U_pgw, V_pgw out; 2 records x S for ua and va; PS
@@ -143,7 +145,7 @@ def main():
         infos.append(info)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {k: ctx.profile_get(k) for k in ('thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'finalize',
+    prof = {k: ctx.profile_get(k) for k in ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'finalize',
                                             'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q',
                                             'pressure', 'time_lerp')}
     micro = microbench(ctx, era, coeffs, a, np) if rank == 0 else {}
@@ -374,7 +376,7 @@ PMC_KERNEL = {'integ_geopot': 'k_integ_geopot', 'adjust_ps_step': 'k_adjust_ps_s
               'vert_interp_delta': 'k_vert_interp_delta', 'q_to_rh': 'k_humidity_hybrid', 'rh_to_q': 'k_humidity_hybrid',
               'finalize': 'k_finalize_ps_hus', 'pressure': 'k_pressure_levels',
               'thermo_delta': 'k_delta_pair<double, 2, true>', 'wind_delta': 'k_delta_pair<double, 2, false>',
-              'phi_ref_hybrid': 'k_phi_ref_hybrid'}
+              'phi_ref_hybrid': 'k_phi_ref_hybrid', 'quad_delta': 'k_delta_quad'}
 
 
 def pmc_traffic(kernel, a):

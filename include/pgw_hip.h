@@ -60,8 +60,8 @@ enum pgw_kernel_id {
     PGW_K_PRESSURE = 0, PGW_K_Q_TO_RH = 1, PGW_K_RH_TO_Q = 2, PGW_K_INTEG_GEOPOT = 3,
     PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
     PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
-    PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13,
-    PGW_K_COUNT = 14
+    PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13, PGW_K_QUAD_DELTA = 14,
+    PGW_K_COUNT = 15
 };
 
 /* ---------------------------------------------------------------- context ------------ */

@@ -741,6 +741,12 @@ static double max_err_of(pgw_ctx *ctx) {
     return m;
 }
 
+static int quad_env() {
+    // default 1: ta+hur and ua+va in ONE kernel (k_delta_quad); PGW_QUAD=0 -> the two pair kernels
+    const char *e = getenv("PGW_QUAD");
+    return (e && e[0] == '0') ? 0 : 1;
+}
+
 static int side_stream_env() {
     // PGW_SIDE_STREAM=1: ua+va pair kernel on the context's side stream.  Default 0: measured gain only 1.5 %
     // (4.96 vs 5.04 ms per file) - either pair kernel alone fills every wave slot, so the two barely co-run -
@@ -1054,6 +1060,32 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                            ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
                            ctx->d_status);                                                                             \
     } while (0)
+        if (quad_env() && !(!check_top && side_stream_env())) {
+            // ---- all four variables in one kernel
+            const size_t qlds = (size_t)2 * N * sizeof(double);
+            if ((rc = status_reset(ctx))) return rc;
+            {
+                Prof pr(ctx, PGW_K_QUAD_DELTA);
+                DISPATCH_T(dtype, {
+                    PairSrc<T> dth{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
+                                   {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
+                    PairSrc<T> ds{{(const T *)a->tas_b, exact ? nullptr : (const T *)a->tas_a, a->x_hi, a->x_new},
+                                  {(const T *)a->hurs_b, exact ? nullptr : (const T *)a->hurs_a, a->x_hi, a->x_new}};
+                    DeltaSrc<T> ph{(const T *)a->pshist_b, exact ? nullptr : (const T *)a->pshist_a, a->x_hi, a->x_new};
+                    PairSrc<T> dwd{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
+                                   {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
+                    hipLaunchKernelGGL((k_delta_quad<T, 2, 128>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
+                                       ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV,
+                                       (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, dwd, check_top,
+                                       (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out, ctx->d_status);
+                });
+            }
+            HIPCHK(ctx, hipGetLastError());
+            if (!defer) {
+                if ((rc = status_check(ctx))) return rc;
+                if ((rc = top_check())) return rc;
+            }
+        } else {
         if ((rc = status_reset(ctx))) return rc;
         HIPCHK(ctx, hipEventRecord(ctx->fork_ev, ctx->stream));      // everything enqueued before this file's kernels
         {
@@ -1093,12 +1125,13 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
             });
         }
         if (side) HIPCHK(ctx, hipEventRecord(ctx->join_ev, ctx->stream2));
-#undef LAUNCH_PAIR
         HIPCHK(ctx, hipGetLastError());
         if (check_top) {
             if ((rc = status_check(ctx))) return rc;
             if ((rc = top_check())) return rc;
         }
+        }   // pair kernels
+#undef LAUNCH_PAIR
     }
 
     // ---- fixed-point loop + final PS, QV

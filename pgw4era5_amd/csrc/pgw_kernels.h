@@ -973,6 +973,199 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
     }
 }
 
+// -------------------------------------------------------------------------------------
+// k_delta_quad: ta + hur AND ua + va in one pass (production kernel of pgw_step03_file).
+// The ta+hur pair is bound by fp64 VALU issue and leaves ~60 % of the HBM bandwidth idle; the
+// ua+va pair is HBM bound and leaves the VALU mostly idle.  In one kernel the two overlap
+// wave by wave (the memory pipe streams U, V while other waves compute e_sat), one ln(p) per
+// level serves all four variables, and the level-loop overhead is paid once.
+// Two source axes are scanned per column: the surface-modified one (ta, hur) and the plain
+// plev axis (ua, va); both use the reference's "first s with sx == x or sx > x" rule.
+// One column per thread, source values gathered on bracket change and cached in registers.
+// -------------------------------------------------------------------------------------
+#ifndef QUAD_MINW
+#define QUAD_MINW 3
+#endif
+template <typename T, int U, int TPB>
+__global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
+                                                       const T *__restrict__ fT, const T *__restrict__ fQ,
+                                                       const T *__restrict__ fU, const T *__restrict__ fV,
+                                                       const T *__restrict__ PS,
+                                                       PairSrc<T> dth, PairSrc<T> dsfc, DeltaSrc<T> psh, PairSrc<T> dw,
+                                                       int check_top, T *__restrict__ oT, T *__restrict__ oE,
+                                                       T *__restrict__ oHur, T *__restrict__ oU, T *__restrict__ oV,
+                                                       DevStatus *st) {
+    extern __shared__ double lds_quad[];            // akm[N] | bkm[N]
+    __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
+    __shared__ int s_nan[TPB / 64];
+    __shared__ double s_lnp[MAX_PLEV];
+    const int S = pt.n;
+    double *s_akm = lds_quad, *s_bkm = lds_quad + lv.nlev;
+    for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
+    for (int i = threadIdx.x; i < lv.nlev; i += TPB) { s_akm[i] = lv.akm[i]; s_bkm[i] = lv.bkm[i]; }
+    __syncthreads();
+    long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
+    double min_t = __builtin_inf(), min_s = __builtin_inf();
+    int nanflag = 0;
+    if (flat < (long long)ntime * ncol) {
+        const int N = lv.nlev;
+        long long t = flat / ncol, c = flat - t * ncol;
+        long long dbase = t * S * ncol + c;
+        long long base = t * N * ncol + c;
+        const double ps = (double)PS[flat];
+        // ---- surface insertion for ta / hur (replace_delta_sfc, functions.py:343-366)
+        int ksfc = -1;
+        bool fill = false;
+        double pshv = psh.get(flat), sfa = dsfc.a.get(flat), sfb = dsfc.b.get(flat);
+        {
+            bool bad = false;
+            if (pshv > pt.pmax) ksfc = S - 1;                                  // :356-359
+            else if (pshv < pt.pmin) bad = true;                              // :360-361
+            else {                                                            // :362-365
+                for (int i = 0; i < S; ++i) if (pshv > pt.p[i]) ksfc = i;
+                if (ksfc < 0) bad = true;
+                fill = true;
+            }
+            if (bad) { report(st, 15, flat); ksfc = -1; fill = false; }
+        }
+        const double lnps = pgw_log(pshv);
+        if (check_top) {                                                      // np.min(source_P), :417
+            for (int i = 0; i < S; ++i) {
+                double p = (i == ksfc) ? pshv : pt.p[i];
+                if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
+            }
+        }
+        auto sx1 = [&](int i) -> double { return (i == ksfc) ? lnps : s_lnp[i]; };      // modified axis
+        auto is_sfc = [&](int i) -> bool { return ksfc >= 0 && (i == ksfc || (fill && i > ksfc)); };
+        // register caches: source levels (ci, ci+1) of each pair
+        int ci1 = -2, ci2 = -2;
+        double a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;       // ta, hur
+        double c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;       // ua, va
+        auto fetch1 = [&](int i1) {
+            if (ci1 == i1) return;
+            long long o = dbase + (long long)(S - 1 - i1) * ncol;
+            if (ci1 + 1 == i1) { a_lo = a_hi; b_lo = b_hi; }
+            else { a_lo = is_sfc(i1) ? sfa : dth.a.get(o); b_lo = is_sfc(i1) ? sfb : dth.b.get(o); }
+            int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+            long long oh = dbase + (long long)(S - 1 - ih) * ncol;
+            a_hi = is_sfc(ih) ? sfa : dth.a.get(oh);
+            b_hi = is_sfc(ih) ? sfb : dth.b.get(oh);
+            ci1 = i1;
+        };
+        auto fetch2 = [&](int i1) {
+            if (ci2 == i1) return;
+            long long o = dbase + (long long)(S - 1 - i1) * ncol;
+            if (ci2 + 1 == i1) { c_lo = c_hi; d_lo = d_hi; }
+            else { c_lo = dw.a.get(o); d_lo = dw.b.get(o); }
+            int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+            long long oh = dbase + (long long)(S - 1 - ih) * ncol;
+            c_hi = dw.a.get(oh);
+            d_hi = dw.b.get(oh);
+            ci2 = i1;
+        };
+        int j1 = 0, j2 = 0;
+        double xprev = -__builtin_inf();
+        // ---- level loop, chunks of U levels with the next chunk's 4*U rows in flight
+        double nT[U], nQ[U], nU[U], nV[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            long long o = base + (long long)(u < N ? u : N - 1) * ncol;
+            nT[u] = (double)fT[o]; nQ[u] = (double)fQ[o]; nU[u] = (double)fU[o]; nV[u] = (double)fV[o];
+        }
+        for (int l0 = 0; l0 < N; l0 += U) {
+            double cT[U], cQ[U], cU[U], cV[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { cT[u] = nT[u]; cQ[u] = nQ[u]; cU[u] = nU[u]; cV[u] = nV[u]; }
+            if (l0 + U < N) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    long long o = base + (long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol;
+                    nT[u] = (double)fT[o]; nQ[u] = (double)fQ[o]; nU[u] = (double)fU[o]; nV[u] = (double)fV[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int l = l0 + u;
+                if (l < N) {
+                    double pa = s_akm[l] + ps * s_bkm[l];                          // step_03:87-88
+                    if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
+                    double x = pgw_log(pa);                                       // functions.py:471
+                    if (!(x >= xprev)) { j1 = 0; j2 = 0; }
+                    while (j1 < S) { double xs = sx1(j1); if (xs == x || xs > x) break; ++j1; }
+                    while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
+                    xprev = (x == x) ? x : __builtin_inf();
+                    // ta, hur on the modified axis
+                    double da, db;
+                    {
+                        int i1, i2;
+                        if (j1 >= S) { i1 = i2 = S - 1; }                          // above range, constant :558-560
+                        else {
+                            double xs = sx1(j1);
+                            if (xs == x) { i1 = i2 = j1; }                         // exact                 :540-543
+                            else if (j1 == 0) { i1 = i2 = 0; }                     // below range, constant :534-536
+                            else { i1 = j1 - 1; i2 = j1; }                         // bracket               :545-548
+                        }
+                        fetch1(i1);
+                        da = a_lo; db = b_lo;
+                        if (i1 != i2) {                                            // :575-578
+                            double x1 = sx1(i1), x2 = sx1(i2);
+                            double dx = x - x1, Dx = x2 - x1;
+                            da = a_lo + dx * (a_hi - a_lo) / Dx;
+                            db = b_lo + dx * (b_hi - b_lo) / Dx;
+                        }
+                    }
+                    // ua, va on the plain plev axis
+                    double dc, dd;
+                    {
+                        int i1, i2;
+                        if (j2 >= S) { i1 = i2 = S - 1; }
+                        else {
+                            double xs = s_lnp[j2];
+                            if (xs == x) { i1 = i2 = j2; }
+                            else if (j2 == 0) { i1 = i2 = 0; }
+                            else { i1 = j2 - 1; i2 = j2; }
+                        }
+                        fetch2(i1);
+                        dc = c_lo; dd = d_lo;
+                        if (i1 != i2) {
+                            double x1 = s_lnp[i1], x2 = s_lnp[i2];
+                            double dx = x - x1, Dx = x2 - x1;
+                            dc = c_lo + dx * (c_hi - c_lo) / Dx;
+                            dd = d_lo + dx * (d_hi - d_lo) / Dx;
+                        }
+                    }
+                    long long o = base + (long long)l * ncol;
+                    oU[o] = (T)(cU[u] + dc);                                       // step_03:170-173
+                    oV[o] = (T)(cV[u] + dd);
+                    double rh_era = q_to_rh(cQ[u], pa, cT[u]);                     // step_03:91-94
+                    double ta_pgw = cT[u] + da;
+                    double hur_pgw = rh_era + db;
+                    oT[o] = (T)ta_pgw;
+                    oE[o] = (T)rh_to_e(hur_pgw, ta_pgw);                           // functions.py:123
+                    if (oHur) oHur[o] = (T)hur_pgw;
+                }
+            }
+        }
+    }
+    if (check_top) {
+        double wt = wave_min(min_t), ws = wave_min(min_s);
+        int wn = nanflag;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wn |= __shfl_xor(wn, off, 64);
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_mint[w] = wt; s_mins[w] = ws; s_nan[w] = wn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mt = s_mint[0], ms = s_mins[0];
+            int nn = s_nan[0];
+            for (int i = 1; i < TPB / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
+            if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
+            if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
+            if (nn) atomicOr(&st->nan_seen, nn);
+        }
+    }
+}
+
 // =====================================================================================
 // a10  bilinear regridding (lat then lon)                      functions.py:817-893
 // One thread per output element, lanes along target lon (coalesced writes; the source grid
