@@ -1060,7 +1060,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                            ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
                            ctx->d_status);                                                                             \
     } while (0)
-        if (quad_env() && !(!check_top && side_stream_env())) {
+        // fp32 storage: both pairs are VALU bound and the 3-waves/SIMD quad kernel measured slower (2.62 vs 2.49 ms)
+        if (quad_env() && dtype == PGW_F64 && !(!check_top && side_stream_env())) {
             // ---- all four variables in one kernel
             const size_t qlds = (size_t)2 * N * sizeof(double);
             if ((rc = status_reset(ctx))) return rc;
