@@ -142,7 +142,7 @@ static inline bool aligned16(const void *p) { return p == nullptr || (((uintptr_
 static int pick_vec(int dtype, long long ncol, std::initializer_list<const void *> ptrs, int max_v = 4) {
     int v = (dtype == PGW_F64) ? 2 : 4;
     if (v > max_v) v = max_v;
-    static const char *force = getenv("PGW_FORCE_VEC1");       // tuning knob: scalar columns per thread
+    const char *force = getenv("PGW_FORCE_VEC1");       // tuning knob: scalar columns per thread
     if (force && force[0] == '1') return 1;
     for (const void *p : ptrs) if (!aligned16(p)) return 1;
     while (v > 1 && ncol % v != 0) v >>= 1;
@@ -694,7 +694,7 @@ extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int npl
 #define STEP_U 2      // measured 3 % faster than 4 for the pass kernel (finer stop above p_ref, fewer VGPRs)
 #endif
 static int step_u() {
-    static const char *e = getenv("PGW_STEP_U");      // tuning knob: levels per pipelined chunk of the pass kernel
+    const char *e = getenv("PGW_STEP_U");      // tuning knob: levels per pipelined chunk of the pass kernel
     return (e && e[0] == '2') ? 2 : STEP_U;
 }
 
@@ -767,12 +767,12 @@ static int device_loop_env() {
 static int pair_staged_env() {
     // tuning knob: 1 = stage the delta source columns in LDS (7 waves/CU at S = 19); default 0 = gather them
     // from global memory when a column's bracket changes (12 waves/CU; measured 25 % faster: 1.85 vs 2.44 ms)
-    static const char *e = getenv("PGW_PAIR_STAGED");
+    const char *e = getenv("PGW_PAIR_STAGED");
     return (e && e[0] == '1') ? 1 : 0;
 }
 
 static int pair_vec_env() {
-    static const char *e = getenv("PGW_PAIR_VEC");     // tuning knob: 16 B per lane in the delta-pair kernels
+    const char *e = getenv("PGW_PAIR_VEC");     // tuning knob: 16 B per lane in the delta-pair kernels
     return (e && e[0] == '1') ? 1 : 0;
 }
 
