@@ -148,8 +148,9 @@ def main():
     prof = {k: ctx.profile_get(k) for k in ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'finalize',
                                             'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q',
                                             'pressure', 'time_lerp')}
-    micro = microbench(ctx, era, coeffs, a, np) if rank == 0 else {}
-    overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a) if (rank == 0 and a.overlap_streams > 1) else None
+    micro = microbench(ctx, era, coeffs, a, np) if (rank == 0 and world == 1) else {}       # N = 1 only: keeps multi-rank runs short
+    overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a) \
+        if (rank == 0 and world == 1 and a.overlap_streams > 1) else None
     ctx.profile(False)
     if dist is not None:
         import torch
@@ -201,7 +202,7 @@ def main():
             'roofline': roof,
             'kernels': kern,
             'signature_kernels': micro,
-            'extras': extras(ctx, case, era, coeffs, deltas, a, np) if a.extras else None,
+            'extras': extras(ctx, case, era, coeffs, deltas, a, np) if (a.extras and world == 1) else None,
             'overlap': overlap,
             'device': ctx.device_name(),
             'setup_s': round(t_gen, 1),
