@@ -75,8 +75,8 @@ def kernel_bytes(name, N, S, ncol, s, info):
         return (3 * N + 1) * ncol * s
     if name == 'rh_to_q':             # hur, ta in, e out (vapour pressure pre-pass)
         return 3 * N * ncol * s
-    if name == 'finalize':            # e in, QV out, PS in/out, delta_ps
-        return 2 * N * ncol * s + ncol * (2 * s + 8)
+    if name == 'finalize':            # e in, QV out (levels the quad kernel has not finalised already), PS in/out, delta_ps
+        return 2 * (N - info.get('qv_done_levels', 0)) * ncol * s + ncol * (2 * s + 8)
     if name == 'pressure':            # ps in, pa_hl out
         return (N + 2) * ncol * s
     return 0
@@ -163,7 +163,13 @@ def main():
         n_iter = [i['n_iter'] for i in infos]
         passes = sum(n_iter)
         lv_per_launch = sum(i['levels_touched'] for i in infos) / max(passes, 1)
-        kinfo = dict(levels_per_launch=lv_per_launch)
+        bk = case['era']['bk']
+        n_pure = 0
+        while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
+            n_pure += 1
+        # pure-pressure levels: their final QV is written by k_delta_quad (fp64 storage, stop-above-p_ref passes)
+        quad = a.storage == 'f64' and not a.full_column and os.environ.get('PGW_QUAD', '1') != '0'
+        kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0)
         kern = {}
         for k, (cnt, ms) in prof.items():
             if cnt == 0:

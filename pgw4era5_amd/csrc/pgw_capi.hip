@@ -29,6 +29,7 @@ struct pgw_ctx {
     double *d_levels = nullptr;        // ak | bk | akm | bkm
     std::vector<double> h_akm, h_bkm;
     double ps_mono_min = 0.0;
+    int n_pure = 0;                    // leading full levels with bkm == 0 (pure-pressure levels)
     // plev table cache for vert_interp_delta
     std::vector<double> plev_key;
     PlevTable plev_tab;
@@ -378,6 +379,8 @@ extern "C" int pgw_set_levels(pgw_ctx *ctx, int nlev, const double *ak, const do
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // h is a stack-lifetime buffer
     ctx->nlev = nlev;
     ctx->ps_mono_min = pmin;
+    ctx->n_pure = 0;
+    while (ctx->n_pure < nlev && pbkm[ctx->n_pure] == 0.0) ctx->n_pure += 1;
     ctx->h_akm.assign(pakm, pakm + nlev);
     ctx->h_bkm.assign(pbkm, pbkm + nlev);
     return PGW_OK;
@@ -837,7 +840,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                        const void *dzg_b, const void *dzg_a, double x_hi, double x_new, double p_ref,
                        double adj_factor, double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
                        double *max_err_hist, int hist_len, int local_nplev = 0, const double *plev_file = nullptr,
-                       const double *akbk_N = nullptr, bool status_armed = false) {
+                       const double *akbk_N = nullptr, bool status_armed = false, int qv_done_levels = 0) {
     const long long n2 = (long long)ntime * ncol;
     void *state = nullptr;
     int rc;
@@ -887,7 +890,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             Prof pr(ctx, PGW_K_FINALIZE);
             DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
                                                         ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
-                                                        (T *)ps_pgw, (T *)hus_pgw));
+                                                        (T *)ps_pgw, (T *)hus_pgw, qv_done_levels));
         }
         HIPCHK(ctx, hipGetLastError());
         LoopState h;
@@ -949,7 +952,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         Prof pr(ctx, PGW_K_FINALIZE);
         DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
                                                     ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
-                                                    (T *)ps_pgw, (T *)hus_pgw));
+                                                    (T *)ps_pgw, (T *)hus_pgw, qv_done_levels));
     }
     HIPCHK(ctx, hipGetLastError());
     return PGW_OK;
@@ -990,6 +993,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     const size_t es = dtype == PGW_F64 ? 8 : 4;
     const int N = a->nlev;
     int rc;
+    int qv_done = 0;          // leading levels whose final QV the quad kernel has already written
     if ((rc = plev_table(ctx, a->nplev, a->plev))) return rc;
     void *evap = nullptr;
     if ((rc = ws_get(ctx, 0, (size_t)ntime * N * ncol * es, &evap))) return rc;
@@ -1064,6 +1068,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         if (quad_env() && dtype == PGW_F64 && !(!check_top && side_stream_env())) {
             // ---- all four variables in one kernel
             const size_t qlds = (size_t)2 * N * sizeof(double);
+            qv_done = full_column_env() ? 0 : ctx->n_pure;     // full-column passes read e at every level
             if ((rc = status_reset(ctx))) return rc;
             {
                 Prof pr(ctx, PGW_K_QUAD_DELTA);
@@ -1078,7 +1083,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                     hipLaunchKernelGGL((k_delta_quad<T, 2, 128>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
                                        ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV,
                                        (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, dwd, check_top,
-                                       (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out, ctx->d_status);
+                                       (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out,
+                                       (T *)a->QV_out, qv_done, ctx->d_status);
                 });
             }
             HIPCHK(ctx, hipGetLastError());
@@ -1150,7 +1156,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                      a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a, a->x_hi,
                      a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
                      a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev, akbk_N,
-                     !check_top && device_loop_env() && !a->local_p_ref);
+                     !check_top && device_loop_env() && !a->local_p_ref, qv_done);
     a->levels_touched = ctx->last_levels_touched;
     if (!check_top && side_stream_env()) {
         // join: later work on the main stream (and the caller after the next synchronisation) sees U_out, V_out

@@ -462,7 +462,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime, long long ncol,
                                                            const T *__restrict__ PS, const double *__restrict__ delta_ps,
                                                            const T *__restrict__ evap, T *__restrict__ ps_out,
-                                                           T *__restrict__ hus_out) {
+                                                           T *__restrict__ hus_out, int l_start) {
     __shared__ double s_lev[LEVTAB_DOUBLES];
     LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
         const int N = lv.nlev;
         long long base = ix.t * N * ncol + ix.c;
 #pragma unroll 4
-        for (int l = 0; l < N; ++l) {
+        for (int l = l_start; l < N; ++l) {            // levels < l_start were written by k_delta_quad
             double e[V], r[V];
             loadv<T, V>(evap + base + (long long)l * ncol, e);
             double am = lt.akm[l], bm = lt.bkm[l];
@@ -994,7 +994,10 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                                                        PairSrc<T> dth, PairSrc<T> dsfc, DeltaSrc<T> psh, PairSrc<T> dw,
                                                        int check_top, T *__restrict__ oT, T *__restrict__ oE,
                                                        T *__restrict__ oHur, T *__restrict__ oU, T *__restrict__ oV,
-                                                       DevStatus *st) {
+                                                       T *__restrict__ oQ, int n_pure, DevStatus *st) {
+    // n_pure > 0: the first n_pure full levels are pure-pressure levels (bkm == 0): their pressure does not depend
+    // on the surface pressure, so the final QV = e_to_q(e, akm) (step_03:262-266,370) is written here already
+    // (instead of e, which only the levels below p_ref and k_finalize_ps_hus need) and the finalize kernel skips them.
     extern __shared__ double lds_quad[];            // akm[N] | bkm[N]
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
@@ -1141,7 +1144,9 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                     double ta_pgw = cT[u] + da;
                     double hur_pgw = rh_era + db;
                     oT[o] = (T)ta_pgw;
-                    oE[o] = (T)rh_to_e(hur_pgw, ta_pgw);                           // functions.py:123
+                    double e_pgw = rh_to_e(hur_pgw, ta_pgw);                       // functions.py:123
+                    if (l < n_pure) oQ[o] = (T)e_to_q(e_pgw, pa);                  // pa == akm[l] for every finite ps
+                    else oE[o] = (T)e_pgw;
                     if (oHur) oHur[o] = (T)hur_pgw;
                 }
             }
