@@ -165,35 +165,199 @@ def _attrs(obj):
     return out
 
 
-def open_dataset(path, decode_times=True):
+def open_dataset(path, decode_times=True, threads=4):
     """Read a NetCDF-3 file completely into memory (`xr.open_dataset(...).load()`).
-    decode_times=False corresponds to the reference's `decode_cf=False` (step_03:60)."""
+    decode_times=False corresponds to the reference's `decode_cf=False` (step_03:60).
+    The file is memory-mapped and every variable is converted to a native-endian array in ONE
+    pass (NetCDF-3 data are big-endian); large variables are converted concurrently (numpy releases
+    the GIL while it copies / byte-swaps)."""
+    from concurrent.futures import ThreadPoolExecutor
     try:
-        nc = netcdf_file(path, 'r', mmap=False)
+        nc = netcdf_file(path, 'r', mmap=True)
     except (TypeError, ValueError) as e:
         raise IOError('%s is not a NetCDF-3 file (%s). NetCDF-4/HDF5 files must be converted, e.g. '
                       '`nccopy -k 64-bit-offset in.nc out.nc`.' % (path, e))
-    ds = Dataset(attrs=_attrs(nc))
-    raw = {}
-    for name, var in nc.variables.items():
-        raw[name] = (np.array(var.data, copy=True), tuple(var.dimensions), _attrs(var))
-    nc.close()
+    try:
+        ds = Dataset(attrs=_attrs(nc))
+        names = list(nc.variables)
+
+        def convert(name):
+            var = nc.variables[name]
+            src = var.data
+            native = src.dtype.newbyteorder('=') if src.dtype.byteorder in ('>', '<') else src.dtype
+            return np.array(src, dtype=native, copy=True, order='C'), tuple(var.dimensions), _attrs(var)
+
+        big = [n for n in names if nc.variables[n].data.nbytes >= (16 << 20)]
+        raw = {}
+        if len(big) > 1 and threads > 1:
+            with ThreadPoolExecutor(max_workers=min(threads, len(big))) as pool:
+                for n, r in zip(big, pool.map(convert, big)):
+                    raw[n] = r
+        for n in names:
+            if n not in raw:
+                raw[n] = convert(n)
+    finally:
+        try:
+            nc.close()
+        except Exception:           # scipy complains if views of the map are still alive; all data were copied
+            pass
     coords = {}
     for name, (data, dims, attrs) in raw.items():
         if dims == (name,):
             if decode_times and 'since' in str(attrs.get('units', '')):
                 data = decode_cf_time(data, attrs['units'], attrs.get('calendar', 'standard'))
             coords[name] = data
-    for name, (data, dims, attrs) in raw.items():
+    for name in names:
+        data, dims, attrs = raw[name]
         if name in coords:
             data = coords[name]
-        if data.dtype.byteorder == '>':
-            data = data.astype(data.dtype.newbyteorder('='))
         ds.variables[name] = Field(data, dims, {d: coords[d] for d in dims if d in coords}, attrs, name)
     return ds
 
 
-def to_netcdf(ds, path):
+_NC_TYPE = {'i1': 1, 'S1': 2, 'i2': 3, 'i4': 4, 'f4': 5, 'f8': 6}
+
+
+def _pad4(b):
+    return b + b'\x00' * (-len(b) % 4)
+
+
+def _nc_name(name):
+    import struct
+    raw = name.encode('utf-8')
+    return struct.pack('>i', len(raw)) + _pad4(raw)
+
+
+def _nc_atts(attrs):
+    import struct
+    if not attrs:
+        return b'\x00' * 8                                   # ABSENT
+    out = struct.pack('>ii', 0x0C, len(attrs))
+    for k, v in attrs.items():
+        out += _nc_name(k)
+        if isinstance(v, bytes):
+            v = v.decode('utf-8', 'replace')
+        if isinstance(v, str):
+            raw = v.encode('utf-8')
+            out += struct.pack('>ii', 2, len(raw)) + _pad4(raw)
+        else:
+            arr = np.atleast_1d(np.asarray(v))
+            if arr.dtype == np.int64:
+                arr = arr.astype(np.int32)
+            if arr.dtype == np.bool_:
+                arr = arr.astype(np.int8)
+            key = arr.dtype.str[1:]
+            if key not in _NC_TYPE or key == 'S1':
+                raw = str(v).encode('utf-8')
+                out += struct.pack('>ii', 2, len(raw)) + _pad4(raw)
+            else:
+                out += struct.pack('>ii', _NC_TYPE[key], arr.size) + _pad4(arr.astype(arr.dtype.newbyteorder('>')).tobytes())
+    return out
+
+
+def to_netcdf(ds, path, threads=4):
+    """Write a Dataset as NetCDF-3 64-bit-offset (`.to_netcdf(path, mode='w')`, step_03:378).
+
+    Native writer (the classic format is a header + fixed-size big-endian arrays): every variable
+    is byte-swapped in one pass and written with `os.pwrite` at its offset, large variables
+    concurrently - scipy's writer makes three copies of every array under the GIL and was the
+    bottleneck of the whole command line (1.06 s per 2.3 GB file; PGW_NC_WRITER=scipy selects it)."""
+    import os
+    import struct
+    from concurrent.futures import ThreadPoolExecutor
+    if os.environ.get('PGW_NC_WRITER') == 'scipy':
+        return _to_netcdf_scipy(ds, path)
+    dims = {}
+    for f in ds.variables.values():
+        for d, n in zip(f.dims, f.shape):
+            if d in dims and dims[d] != int(n):
+                raise ValueError('dimension %s has inconsistent lengths %d and %d' % (d, dims[d], n))
+            dims.setdefault(d, int(n))
+    dim_ids = {d: i for i, d in enumerate(dims)}
+    # variables: data converted lazily (dtype decided here)
+    specs = []
+    for name, f in ds.variables.items():
+        data = f.values
+        attrs = dict(f.attrs)
+        if data.dtype.kind == 'M':
+            data = (data.astype('datetime64[s]') - np.datetime64('1970-01-01T00:00:00', 's')).astype(np.float64)
+            attrs['units'] = 'seconds since 1970-01-01 00:00:00'
+            attrs['calendar'] = 'proleptic_gregorian'
+        if data.dtype == np.int64:
+            data = data.astype(np.int32)
+        if data.dtype == np.bool_:
+            data = data.astype(np.int8)
+        key = data.dtype.str[1:]
+        if key not in _NC_TYPE or key == 'S1':
+            raise TypeError('variable %s: dtype %s cannot be stored in NetCDF-3' % (name, data.dtype))
+        nbytes = int(data.size) * data.dtype.itemsize
+        specs.append(dict(name=name, f=f, data=data, attrs=attrs, key=key, nbytes=nbytes, vsize=nbytes + (-nbytes % 4)))
+
+    def header(begins):
+        h = b'CDF\x02' + struct.pack('>i', 0)
+        if dims:
+            h += struct.pack('>ii', 0x0A, len(dims))
+            for d, n in dims.items():
+                h += _nc_name(d) + struct.pack('>i', n)
+        else:
+            h += b'\x00' * 8
+        h += _nc_atts(ds.attrs)
+        if specs:
+            h += struct.pack('>ii', 0x0B, len(specs))
+            for sp, b in zip(specs, begins):
+                h += _nc_name(sp['name']) + struct.pack('>i', len(sp['f'].dims))
+                for d in sp['f'].dims:
+                    h += struct.pack('>i', dim_ids[d])
+                h += _nc_atts(sp['attrs'])
+                h += struct.pack('>ii', _NC_TYPE[sp['key']], min(sp['vsize'], 0xFFFFFFFF - 3) if sp['vsize'] < 2 ** 32 else -1)
+                h += struct.pack('>q', b)
+        else:
+            h += b'\x00' * 8
+        return h
+
+    hlen = len(header([0] * len(specs)))
+    begins, off = [], hlen
+    for sp in specs:
+        begins.append(off)
+        off += sp['vsize']
+    hdr = header(begins)
+    assert len(hdr) == hlen
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        os.ftruncate(fd, off)
+        os.pwrite(fd, hdr, 0)
+        CH = 64 << 20                                            # swap + write in 64 MiB pieces
+
+        def write_var(i):
+            sp, b = specs[i], begins[i]
+            flat = np.ascontiguousarray(sp['data']).reshape(-1)
+            be = flat.dtype.newbyteorder('>')
+            step = max(CH // max(flat.dtype.itemsize, 1), 1)
+            pos = b
+            for s0 in range(0, flat.size, step):
+                chunk = flat[s0:s0 + step].astype(be)              # one pass: copy + byte swap
+                mv = memoryview(chunk).cast('B')
+                while len(mv):
+                    n = os.pwrite(fd, mv, pos)
+                    pos += n
+                    mv = mv[n:]
+            # padding bytes are already zero (ftruncate)
+
+        big = [i for i, sp in enumerate(specs) if sp['nbytes'] >= (16 << 20)]
+        if len(big) > 1 and threads > 1:
+            with ThreadPoolExecutor(max_workers=min(threads, len(big))) as pool:
+                list(pool.map(write_var, big))
+        else:
+            for i in big:
+                write_var(i)
+        for i in range(len(specs)):
+            if i not in big:
+                write_var(i)
+    finally:
+        os.close(fd)
+
+
+def _to_netcdf_scipy(ds, path):
     """Write a Dataset as NetCDF-3 64-bit-offset (`.to_netcdf(path, mode='w')`, step_03:378)."""
     nc = netcdf_file(path, 'w', version=2)
     for k, v in ds.attrs.items():

@@ -45,8 +45,8 @@ def run_shard(func, tasks, indices, depth=None, io_threads=None):
     if not stages or len(indices) < 2:
         return [(i, func(**tasks[i])) for i in indices]
     from concurrent.futures import ThreadPoolExecutor
-    # measured end to end (fp32 2.3 GB files): 1.92 / 1.60 / 1.42 / 1.41 s per file with 1 / 2 / 3 / 4 I/O threads
-    io_threads = int(os.environ.get('PGW_IO_THREADS', '3')) if io_threads is None else io_threads
+    # stage threads; the NetCDF reader / writer are themselves multi-threaded per file (ncio.py)
+    io_threads = int(os.environ.get('PGW_IO_THREADS', '2')) if io_threads is None else io_threads
     depth = io_threads + 1 if depth is None else depth
     load, compute, store = stages
     results = []
