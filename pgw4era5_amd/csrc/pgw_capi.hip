@@ -492,16 +492,18 @@ static int launch_integ_geopot(pgw_ctx *ctx, int dtype, int nlev, int ntime, lon
                                const void *p_ref_field, void *phi_ref, int full_column, bool out_f64 = false) {
     int vec = pick_vec(dtype, ncol, {pa_hl, zgs, ta, hus, p_ref_field, phi_ref});
     Prof pr(ctx, PGW_K_INTEG_GEOPOT);
-    if (out_f64)
-        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, 4, double>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                    dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,
-                                                    (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,
-                                                    (const T *)p_ref_field, (double *)phi_ref, full_column, ctx->d_status));
-    else
-        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, 4, T>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                    dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,
-                                                    (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,
-                                                    (const T *)p_ref_field, (T *)phi_ref, full_column, ctx->d_status));
+#define LAUNCH_GEO(UU, TO_)                                                                                         \
+    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, UU, TO_>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)), \
+                                                dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,     \
+                                                (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,                  \
+                                                (const T *)p_ref_field, (TO_ *)phi_ref, full_column, ctx->d_status))
+    const char *gu = getenv("PGW_GEO_U");          // tuning knob: levels per chunk of the signature-faithful kernel
+    int u = gu ? atoi(gu) : 4;
+    if (out_f64) { LAUNCH_GEO(4, double); }
+    else if (u == 2) { LAUNCH_GEO(2, T); }
+    else if (u == 8) { LAUNCH_GEO(8, T); }
+    else { LAUNCH_GEO(4, T); }
+#undef LAUNCH_GEO
     return PGW_OK;
 }
 

@@ -231,3 +231,59 @@ def test_loop_converges_and_is_self_consistent():
     pa_hl, pa = O.hybrid_pressure(era['ak'], era['bk'], out['PS'], akm, bkm)
     np.testing.assert_allclose(O.relative_to_specific_humidity(out['RELHUM_pgw'], pa, out['T']), out['QV'],
                                rtol=1e-14)
+
+
+# ---------------- independent numerical cross-checks of the xarray-bound restatements ----------------
+def test_interp_constant_mode_equals_numpy_interp():
+    """'constant' extrapolation == np.interp in ln p (np.interp clamps to the edge values): an independent
+    implementation of the same piecewise-linear rule (functions.py:434-580 with extrapolate='constant')."""
+    rng = np.random.default_rng(17)
+    ps = np.sort(rng.uniform(100, 1e5, (1, 19, 3, 4)), axis=1)
+    pt = np.sort(rng.uniform(20, 1.08e5, (1, 60, 3, 4)), axis=1)
+    v = rng.normal(size=ps.shape)
+    got = O.interp_logp_4d(v, ps, pt, 'constant')
+    for j in range(3):
+        for i in range(4):
+            want = np.interp(np.log(pt[0, :, j, i]), np.log(ps[0, :, j, i]), v[0, :, j, i])
+            np.testing.assert_allclose(got[0, :, j, i], want, rtol=1e-12, atol=1e-13)
+
+
+def test_regrid_equals_scipy_bilinear_in_the_interior():
+    """Separable lat-then-lon linear interpolation == joint bilinear interpolation (scipy
+    RegularGridInterpolator) wherever no pole row / periodic copy is involved."""
+    from scipy.interpolate import RegularGridInterpolator
+    rng = np.random.default_rng(19)
+    slat = np.linspace(-88.5, 88.5, 60); slon = np.arange(0, 360, 3.0)
+    f = rng.normal(size=(60, 120))
+    tlat = np.linspace(-80, 80, 33); tlon = np.linspace(1.0, 355.0, 71)
+    got = O.regrid_lat_lon(f[None], slat, slon, tlat, tlon)[0]
+    rgi = RegularGridInterpolator((slat, slon), f, method='linear')
+    la, lo = np.meshgrid(tlat, tlon, indexing='ij')
+    want = rgi(np.stack([la.ravel(), lo.ravel()], axis=1)).reshape(la.shape)
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12)
+
+
+def test_integ_geopot_against_literal_column_loop():
+    """The level-wise vectorised oracle against a literal per-column transcription of SURVEY appendix A1
+    (scalar Python, no numpy broadcasting): guards the vectorisation, not the reading of the reference."""
+    import math
+    rng = np.random.default_rng(23)
+    ak, bk = _levels(25)
+    ps = rng.uniform(55000, 104000, (1, 3, 4)); fis = rng.uniform(0, 40000, (1, 3, 4))
+    pa_hl, pa = O.hybrid_pressure(ak, bk, ps)
+    T = 220 + 70 * (pa / 1e5) + rng.normal(size=pa.shape); q = rng.uniform(0, 0.02, pa.shape)
+    p_ref = 30000.0
+    got = O.integ_geopot(pa_hl, fis, T, q, np.arange(1, 27), p_ref)
+    n = 25
+    for j in range(3):
+        for i in range(4):
+            p = [x if x > 0 else 1e-4 for x in pa_hl[0, :, j, i]]
+            tv = [T[0, l, j, i] * (1 + 0.61 * q[0, l, j, i]) for l in range(n)]
+            phi = [0.0] * (n + 1)
+            phi[n] = fis[0, j, i]
+            for l in range(n - 1, -1, -1):
+                phi[l] = phi[l + 1] + (O.CON_RD * tv[l] * (math.log(p[l + 1]) - math.log(p[l])))
+            d = [(p[k] - p_ref) if (p[k] - p_ref) >= 0 else float('nan') for k in range(n + 1)]
+            ks = min((k for k in range(n + 1) if d[k] == d[k]), key=lambda k: d[k])
+            want = phi[ks] - (O.CON_RD * tv[ks - 1]) * (math.log(p_ref) - math.log(p[ks]))
+            assert abs(got[0, j, i] - want) <= 1e-9 * abs(want)
