@@ -20,6 +20,8 @@ struct pgw_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // side stream: the HBM-bound wind pair runs beside the VALU-bound ta+hur pair
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    LoopState *h_loop = nullptr;       // pinned ring of 3 read-backs of the device loop state
+    hipEvent_t loop_ev[3] = {nullptr, nullptr, nullptr};
     std::string err;
     long long err_col = -1;
     DevStatus *d_status = nullptr;     // device
@@ -225,6 +227,10 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(&c->h_loop, 3 * sizeof(LoopState)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->loop_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->loop_ev[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->loop_ev[2], hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->d_status, sizeof(DevStatus)) != hipSuccess ||
         hipHostMalloc(&c->h_status, sizeof(DevStatus)) != hipSuccess ||
         hipMalloc(&c->d_small, SMALL_BYTES) != hipSuccess ||
@@ -252,6 +258,8 @@ extern "C" int pgw_ctx_destroy(pgw_ctx *ctx) {
     if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
     if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
     if (ctx->join_ev) hipEventDestroy(ctx->join_ev);
+    for (int i = 0; i < 3; ++i) if (ctx->loop_ev[i]) hipEventDestroy(ctx->loop_ev[i]);
+    if (ctx->h_loop) hipHostFree(ctx->h_loop);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PGW_OK;
@@ -761,12 +769,17 @@ static int side_stream_env() {
 }
 
 static int device_loop_env() {
-    // PGW_DEVICE_LOOP=1: all max_n_iter passes are enqueued back to back and controlled on the device (one host
-    // synchronisation per file).  Default 0: the host reads max|err| after every pass - the reference's control
-    // flow literally, and measured FASTER (4.82 vs 5.50 ms per file): with ~6 passes needed, the 14 no-op
-    // launches (+ their profiling events) cost more than the 6 round trips they save.
+    // Loop control (fixed p_ref), PGW_DEVICE_LOOP:
+    //   0 (default): the host reads max|err| after every pass before launching the next (the reference's flow
+    //      literally); 4.55 ms per 1440x721xL137 file;
+    //   2: one pass ahead - pass k+1 is enqueued before the host has read pass k; a device-side `done` flag turns
+    //      the single speculated pass after convergence into a no-op.  Measured 4.69 ms: the speculated launch and
+    //      the per-pass read-back copies + events cost more than the ~10 us round trips they hide;
+    //   1: all max_n_iter passes enqueued back to back (measured slowest: 14 no-op launches per file).
     const char *e = getenv("PGW_DEVICE_LOOP");
-    return (e && e[0] == '1') ? 1 : 0;
+    if (e && e[0] == '1') return 1;
+    if (e && e[0] == '2') return 2;
+    return 0;
 }
 
 static int pair_staged_env() {
@@ -873,7 +886,62 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     }
     HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
 
-    if (!local && device_loop_env()) {
+    if (!local && device_loop_env() == 2) {
+        // One pass ahead: pass k+1 is enqueued BEFORE the host has seen the result of pass k, so the GPU never
+        // idles for a host round trip.  Every pass first checks the device-side `done` flag (set by the last
+        // block of the pass that reached max|err| <= thresh) and returns at once if it is set, so the one
+        // speculated pass after convergence changes nothing.  The host follows one pass behind through a
+        // pinned read-back ring and applies the reference's control flow (step_03:189, 313-319) to what it reads.
+        NEED(ctx, max_n_iter <= 32, "max_n_iter must be <= 32 for the device-assisted loop");
+        void *lsv = nullptr;
+        if ((rc = ws_get(ctx, 4, sizeof(LoopState), &lsv))) return rc;
+        LoopState *ls = (LoopState *)lsv;
+        HIPCHK(ctx, hipMemsetAsync(ls, 0, sizeof(LoopState), ctx->stream));
+        auto enqueue_pass = [&](int slot) -> int {
+            launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
+                        adj_factor, full_column, 1, ls, thresh);
+            HIPCHK(ctx, hipMemcpyAsync(&ctx->h_loop[slot], ls, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipEventRecord(ctx->loop_ev[slot], ctx->stream));
+            return PGW_OK;
+        };
+        if ((rc = enqueue_pass(0))) return rc;
+        unsigned long long touched = 0;
+        int passes = 0;
+        bool converged = false, too_many = false;
+        for (int k = 0;; ++k) {
+            if ((rc = enqueue_pass((k + 1) % 3))) return rc;                // speculative next pass
+            HIPCHK(ctx, hipEventSynchronize(ctx->loop_ev[k % 3]));
+            const LoopState &h = ctx->h_loop[k % 3];                        // state after pass k
+            passes = k + 1;
+            if (k < 32) {
+                touched += h.levels[k];
+                if (max_err_hist && k < hist_len) max_err_hist[k] = h.max_err[k];
+            }
+            if (k + 2 > max_n_iter) { too_many = true; break; }            // it += 1 ; if it > max_n_iter: raise   :313-319
+            if (h.done) { converged = true; break; }                        // while phi_ref_max_error > thresh      :189
+        }
+        (void)converged;
+        ctx->last_levels_touched = touched;
+        if (n_iter) *n_iter = passes;
+        if (!too_many && (ps_pgw || hus_pgw)) {
+            int vec = pick_vec(dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
+            Levels lv = levels_of(ctx);
+            Prof pr(ctx, PGW_K_FINALIZE);
+            DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                                        ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
+                                                        (T *)ps_pgw, (T *)hus_pgw, qv_done_levels));
+        }
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = status_check(ctx))) return rc;                            // kernel-reported data errors first
+        if (too_many) {
+            ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
+            ctx->err_col = -1;
+            return PGW_ERR_NOT_CONVERGED;
+        }
+        return PGW_OK;
+    }
+
+    if (!local && device_loop_env() == 1) {
         // All passes are enqueued back to back; each one checks the device-side `done` flag and the block
         // that finishes a pass last publishes max|err| (k_adjust_ps_step).  The reference raises when the pass
         // counter exceeds max_n_iter even if that pass converged (step_03:313-319), i.e. max_n_iter passes can

@@ -503,13 +503,16 @@ def test_reinterp_mode_vs_oracle(dtype):
     assert np.abs(base['T'] - got['T']).max() > 1e-6
 
 
-def test_device_controlled_loop_matches_host_controlled(monkeypatch):
-    """PGW_DEVICE_LOOP=1 (passes enqueued back to back, `done` flag and max|err| kept on the device)
-    gives bit-identical results and the same iteration count as the host-controlled loop."""
+@pytest.mark.parametrize('mode', ['1', '2'])
+def test_device_controlled_loop_matches_host_controlled(monkeypatch, mode):
+    """The three loop-control variants - default: the host reads max|err| before every launch (the
+    reference's flow literally); PGW_DEVICE_LOOP=2: one pass enqueued ahead of the host with a
+    device-side `done` flag; =1: all passes enqueued back to back - give bit-identical results, the
+    same iteration count and the same non-convergence error."""
     from pgw4era5_amd import step_03_apply_to_era as s3
     c = _case(9, 16, 30, seed=41)
     a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
-    monkeypatch.setenv('PGW_DEVICE_LOOP', '1')
+    monkeypatch.setenv('PGW_DEVICE_LOOP', mode)
     b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
     assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
     for k in ['PS', 'T', 'QV', 'U', 'V']:
