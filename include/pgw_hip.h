@@ -61,7 +61,7 @@ enum pgw_kernel_id {
     PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
     PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
     PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13, PGW_K_QUAD_DELTA = 14,
-    PGW_K_COUNT = 15
+    PGW_K_BYTESWAP = 15, PGW_K_COUNT = 16
 };
 
 /* ---------------------------------------------------------------- context ------------ */
@@ -299,6 +299,12 @@ int pgw_surface_update(pgw_ctx *ctx, int dtype, int ntime, long long ncol, int n
                        const void *sic, const void *dsic, const void *dtos, const void *dts,
                        const void *land, const void *ts_clim, const void *tskin, const void *tso,
                        void *sic_out, void *dts_comb_out, void *tskin_out, void *tso_out);
+
+/* Byte-order conversion on the device: dst[i] = byte-reversed src[i] for n elements of 4 or 8 bytes (in place
+ * allowed).  NetCDF classic files are big-endian (the reference reads / writes them through xarray,
+ * step_03_apply_to_era.py:60, 378, which converts on the host); with this entry the raw file bytes are uploaded
+ * and converted at HBM speed, and results are converted before the download, so no host pass touches the fields. */
+int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst);
 
 /* diagnostic: out[i] = ln(in[i]) with the device logarithm every kernel uses (pgw_device.h
  * pgw_log: fdlibm log kernel for positive normal finite x, ocml log otherwise); device fp64 arrays */

@@ -288,6 +288,7 @@ extern "C" int pgw_free(pgw_ctx *ctx, void *dptr) {
     return PGW_OK;
 }
 extern "C" int pgw_host_alloc(pgw_ctx *ctx, size_t bytes, void **hptr) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));                  // callable from reader / writer threads
     HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 16));
     return PGW_OK;
 }
@@ -1238,6 +1239,27 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
 }
 
 extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx->last_levels_touched; }
+
+extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst) {
+    NEED(ctx, elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 or 8");
+    NEED(ctx, n >= 0 && (n == 0 || (src && dst)), "bad argument");
+    if (n == 0) return PGW_OK;
+    NEED(ctx, ((uintptr_t)src % elem_bytes) == 0 && ((uintptr_t)dst % elem_bytes) == 0, "pointers must be element-aligned");
+    const bool al16 = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0;
+    const long long n16 = al16 ? n / (16 / elem_bytes) : 0;
+    const long long work = al16 ? (n16 ? n16 : 1) : n;
+    unsigned int nb = nblocks(work, BLOCK);
+    if (nb > 256 * 16) nb = 256 * 16;
+    {
+        Prof pr(ctx, PGW_K_BYTESWAP);
+        if (elem_bytes == 4)
+            hipLaunchKernelGGL((k_byteswap<4>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n16, n, (const uint4 *)src, (uint4 *)dst);
+        else
+            hipLaunchKernelGGL((k_byteswap<8>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n16, n, (const uint4 *)src, (uint4 *)dst);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
 
 extern "C" int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out) {
     NEED(ctx, n >= 1 && in && out, "bad argument");

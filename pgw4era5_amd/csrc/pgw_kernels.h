@@ -1464,6 +1464,34 @@ __global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long l
     }
 }
 
+// Byte-order conversion of a field (NetCDF classic data are big-endian): every 4- or 8-byte element of `src` is
+// written byte-reversed to `dst` (in place allowed), 16 B per lane, grid-stride.  HBM-bound: 2 x n x W bytes.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_byteswap(long long n16, long long n, const uint4 *src, uint4 *dst) {   // may alias
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        uint4 v = src[i];
+        if (W == 4) {
+            v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
+            v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
+        } else {
+            unsigned int a = __builtin_bswap32(v.y), b = __builtin_bswap32(v.x);
+            unsigned int c = __builtin_bswap32(v.w), d = __builtin_bswap32(v.z);
+            v.x = a; v.y = b; v.z = c; v.w = d;
+        }
+        dst[i] = v;
+    }
+    // tail elements (n not a multiple of 16 / W) and the unaligned case (n16 == 0): element by element
+    const long long done = n16 * (16 / W);
+    for (long long e = done + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        if (W == 4) {
+            ((unsigned int *)dst)[e] = __builtin_bswap32(((const unsigned int *)src)[e]);
+        } else {
+            ((unsigned long long *)dst)[e] = __builtin_bswap64(((const unsigned long long *)src)[e]);
+        }
+    }
+}
+
 // pgw_log over an array (diagnostic entry pgw_test_log; tests compare it with numpy's log)
 __global__ void k_test_log(long long n, const double *__restrict__ in, double *__restrict__ out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -13,6 +13,8 @@ import numpy as np
 
 from . import _lib
 
+_FOREIGN = '>' if np.little_endian else '<'      # numpy byteorder code of the non-native order
+
 _DTYPE_TAG = {np.dtype('float32'): _lib.PGW_F32, np.dtype('float64'): _lib.PGW_F64}
 
 
@@ -58,14 +60,38 @@ class DeviceArray:
             self.ctx.sync()
         return out
 
-    def copy_from(self, host):
-        host = np.ascontiguousarray(host, dtype=self.dtype)
+    def copy_from(self, host, sync=True):
+        """Upload a host array.  An array in the file's byte order (e.g. '>f4' from `ncio.open_dataset(raw_big=True)`)
+        of the same element size is uploaded as it is and converted on the device (`pgw_byteswap`), so the host
+        never touches the values.  sync=False: the caller synchronises the context before `host` may be reused
+        (meant for pinned sources, where the copy is a real asynchronous DMA)."""
+        host = np.asarray(host)
+        swapped = (host.dtype.byteorder == _FOREIGN and host.dtype.kind == self.dtype.kind
+                   and host.dtype.itemsize == self.dtype.itemsize and host.flags.c_contiguous)
+        if not swapped:
+            host = np.ascontiguousarray(host, dtype=self.dtype)
         if host.shape != self.shape:
             raise ValueError('shape mismatch %s vs %s' % (host.shape, self.shape))
         if self.nbytes:
             self.ctx._check(self.ctx.lib.pgw_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes))
-            self.ctx.sync()          # pageable source: keep it alive until the copy is done
+            if swapped:
+                self.ctx._check(self.ctx.lib.pgw_byteswap(self.ctx.handle, self.dtype.itemsize, self.size, self.ptr, self.ptr))
+            if sync:
+                self.ctx.sync()      # pageable source: keep it alive until the copy is done
         return self
+
+    def download_foreign(self, host_bytes, scratch=None):
+        """Enqueue: convert to the file's (big-endian) byte order on the device - into `scratch` if given, else in
+        place, which leaves this array byte-reversed - and copy to the writable uint8 host buffer.  No
+        synchronisation: the caller calls `ctx.sync()` before reading `host_bytes`.  Returns the host buffer viewed
+        with the big-endian dtype and this array's shape."""
+        if host_bytes.nbytes < self.nbytes:
+            raise ValueError('host buffer too small')
+        dst = self.ptr if scratch is None else scratch.ptr
+        if self.nbytes:
+            self.ctx._check(self.ctx.lib.pgw_byteswap(self.ctx.handle, self.dtype.itemsize, self.size, self.ptr, dst))
+            self.ctx._check(self.ctx.lib.pgw_memcpy_d2h(self.ctx.handle, host_bytes.ctypes.data, dst, self.nbytes))
+        return host_bytes[:self.nbytes].view(self.dtype.newbyteorder(_FOREIGN)).reshape(self.shape)
 
     def view(self, shape):
         """Reshaped alias of the same buffer."""
@@ -200,14 +226,66 @@ class Context:
         self.nlev = len(ak) - 1
 
 
+class PinnedPool:
+    """Reusable pinned (page-locked) host buffers of one context: the reader threads `pread` file bytes into
+    them, the GPU stage DMAs from / to them, the writer threads `pwrite` from them.  Pinning 2 GB costs far
+    more than a copy, so buffers are recycled by size; thread-safe."""
+
+    def __init__(self, ctx):
+        import threading
+        self.ctx = ctx
+        self._free = {}
+        self._owned = {}                  # address -> (rounded size, base array)
+        self._lock = threading.Lock()
+        self.allocated = 0
+
+    def acquire(self, nbytes):
+        size = max((int(nbytes) + (1 << 20) - 1) >> 20 << 20, 1 << 20)
+        with self._lock:
+            lst = self._free.get(size)
+            if lst:
+                return lst.pop()
+        p = C.c_void_p()
+        self.ctx._check(self.ctx.lib.pgw_host_alloc(self.ctx.handle, size, C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_ubyte * size).from_address(p.value))
+        with self._lock:
+            self._owned[p.value] = (size, arr)
+            self.allocated += size
+        return arr
+
+    def release(self, arr):
+        """Give a buffer (or any view that starts at its first byte) back."""
+        addr = arr.ctypes.data
+        with self._lock:
+            ent = self._owned.get(addr)
+            if ent is None:
+                return False
+            self._free.setdefault(ent[0], []).append(ent[1])
+        return True
+
+    def owns(self, arr):
+        return arr.ctypes.data in self._owned
+
+    def close(self):
+        with self._lock:
+            for addr in list(self._owned):
+                self.ctx.lib.pgw_host_free(self.ctx.handle, addr)
+            self._owned.clear()
+            self._free.clear()
+            self.allocated = 0
+
+
 _default = None
+_default_lock = __import__('threading').Lock()
 
 
 def default_context():
-    """Process-wide context (device = LOCAL_RANK, one process per GPU)."""
+    """Process-wide context (device = LOCAL_RANK, one process per GPU); safe to call from the I/O threads."""
     global _default
     if _default is None:
-        _default = Context()
+        with _default_lock:
+            if _default is None:
+                _default = Context()
     return _default
 
 

@@ -165,12 +165,194 @@ def _attrs(obj):
     return out
 
 
-def open_dataset(path, decode_times=True, threads=4):
+# NetCDF classic header (CDF-1 / CDF-2 / CDF-5), parsed here so that the reader knows every variable's byte
+# range and can `pread` it straight into a caller-supplied (pinned) buffer.
+_NC_DTYPE = {1: 'i1', 2: 'S1', 3: 'i2', 4: 'i4', 5: 'f4', 6: 'f8', 7: 'u1', 8: 'u2', 9: 'u4', 10: 'i8', 11: 'u8'}
+BIG_VARIABLE = 16 << 20                  # bytes; larger variables are read concurrently / kept raw on request
+
+
+class _Cursor:
+    def __init__(self, fd):
+        self.fd, self.buf, self.pos = fd, b'', 0
+
+    def take(self, n):
+        import os
+        while self.pos + n > len(self.buf):
+            more = os.pread(self.fd, max(1 << 20, self.pos + n - len(self.buf)), len(self.buf))
+            if not more:
+                raise ValueError('truncated header')
+            self.buf += more
+        out = self.buf[self.pos:self.pos + n]
+        self.pos += n
+        return out
+
+    def i32(self):
+        return int.from_bytes(self.take(4), 'big', signed=True)
+
+    def i64(self):
+        return int.from_bytes(self.take(8), 'big', signed=True)
+
+
+def _parse_header(fd, file_size):
+    """-> dict(version, numrecs, dims [(name, len)], attrs, vars [dict(name, dims, attrs, dtype, begin, shape,
+    record, nbytes)], recsize).  `nbytes` is per record for record variables."""
+    c = _Cursor(fd)
+    magic = c.take(4)
+    if magic[:3] != b'CDF' or magic[3] not in (1, 2, 5):
+        raise ValueError('magic %r' % magic)
+    version = magic[3]
+    nonneg = c.i64 if version == 5 else c.i32
+
+    def name():
+        n = nonneg()
+        raw = c.take(n)
+        c.take(-n % 4)
+        return raw.decode('utf-8', 'replace')
+
+    def att_list():
+        tag = c.i32()
+        n = nonneg()
+        if tag == 0:
+            return {}
+        if tag != 0x0C:
+            raise ValueError('attribute list tag %#x' % tag)
+        out = {}
+        for _ in range(n):
+            k = name()
+            t = c.i32()
+            cnt = nonneg()
+            if t not in _NC_DTYPE:
+                raise ValueError('attribute type %d' % t)
+            dt = np.dtype(_NC_DTYPE[t])
+            raw = c.take(cnt * dt.itemsize)
+            c.take(-(cnt * dt.itemsize) % 4)
+            if t == 2:
+                out[k] = raw.rstrip(b'\x00').decode('utf-8', 'replace')
+            else:
+                v = np.frombuffer(raw, dtype=dt.newbyteorder('>')).astype(dt)
+                out[k] = v[0] if v.shape == (1,) else v
+        return out
+
+    numrecs = nonneg()
+    if version != 5 and numrecs == -1:
+        numrecs = None                                           # STREAMING: derived from the file size below
+    tag, n = c.i32(), nonneg()
+    if tag not in (0, 0x0A):
+        raise ValueError('dimension list tag %#x' % tag)
+    dims = [(name(), nonneg()) for _ in range(n if tag else 0)]
+    gatts = att_list()
+    tag, n = c.i32(), nonneg()
+    if tag not in (0, 0x0B):
+        raise ValueError('variable list tag %#x' % tag)
+    variables = []
+    for _ in range(n if tag else 0):
+        vname = name()
+        nd = nonneg()
+        dimids = [nonneg() for _ in range(nd)]
+        vatts = att_list()
+        t = c.i32()
+        nonneg()                                                 # vsize: unreliable for > 4 GiB, recomputed
+        begin = c.i32() if version == 1 else c.i64()
+        if t not in _NC_DTYPE:
+            raise ValueError('variable type %d' % t)
+        dt = np.dtype(_NC_DTYPE[t])
+        record = nd > 0 and dims[dimids[0]][1] == 0
+        shape = [dims[i][1] for i in dimids]
+        inner = int(np.prod(shape[1:] if record else shape, dtype=np.int64))
+        variables.append(dict(name=vname, dims=tuple(dims[i][0] for i in dimids), attrs=vatts, dtype=dt, begin=begin,
+                              shape=shape, record=record, nbytes=inner * dt.itemsize))
+    recs = [v for v in variables if v['record']]
+    if len(recs) == 1:
+        recsize = recs[0]['nbytes']                              # a single record variable is not padded
+    else:
+        recsize = sum(v['nbytes'] + (-v['nbytes'] % 4) for v in recs)
+    if recs and numrecs is None:
+        numrecs = (file_size - min(v['begin'] for v in recs)) // recsize if recsize else 0
+    for v in recs:
+        v['shape'][0] = numrecs or 0
+    return dict(version=version, numrecs=numrecs or 0, dims=dims, attrs=gatts, vars=variables, recsize=recsize)
+
+
+def _pread_into(fd, buf, offset):
+    """Fill the writable byte buffer from the file (the kernel copies from the page cache straight into `buf`;
+    the GIL is released during the call)."""
+    import os
+    mv = memoryview(buf).cast('B')
+    while len(mv):
+        n = os.preadv(fd, [mv[:1 << 30]], offset)
+        if n <= 0:
+            raise IOError('unexpected end of file')
+        offset += n
+        mv = mv[n:]
+
+
+def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None):
     """Read a NetCDF-3 file completely into memory (`xr.open_dataset(...).load()`).
     decode_times=False corresponds to the reference's `decode_cf=False` (step_03:60).
-    The file is memory-mapped and every variable is converted to a native-endian array in ONE
-    pass (NetCDF-3 data are big-endian); large variables are converted concurrently (numpy releases
-    the GIL while it copies / byte-swaps)."""
+
+    Every variable is `pread` into its array (large ones concurrently) and converted from the file's big-endian
+    layout in place.  With `raw_big=True` variables of at least BIG_VARIABLE bytes are NOT converted: their
+    `.values` keep the big-endian dtype of the file ('>f4'), for `DeviceArray.copy_from` to convert on the GPU;
+    `alloc(nbytes) -> writable uint8 array` supplies their buffers (pinned host memory in the step_03 driver).
+    PGW_NC_READER=scipy selects the previous reader built on scipy.io.netcdf_file."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if os.environ.get('PGW_NC_READER') == 'scipy':
+        return _open_dataset_scipy(path, decode_times, threads)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        try:
+            hdr = _parse_header(fd, os.fstat(fd).st_size)
+        except (ValueError, IndexError) as e:
+            raise IOError('%s is not a NetCDF-3 file (%s). NetCDF-4/HDF5 files must be converted, e.g. '
+                          '`nccopy -k 64-bit-offset in.nc out.nc`.' % (path, e))
+
+        def read(v):
+            dt = v['dtype']
+            nrec = hdr['numrecs'] if v['record'] else 1
+            total = v['nbytes'] * nrec
+            big = total >= BIG_VARIABLE
+            if big and alloc is not None:
+                buf = alloc(total)[:total]
+            else:
+                buf = np.empty(total, dtype=np.uint8)
+            for r in range(nrec):
+                if v['nbytes']:
+                    _pread_into(fd, buf[r * v['nbytes']:(r + 1) * v['nbytes']], v['begin'] + r * hdr['recsize'])
+            arr = buf.view(dt.newbyteorder('>') if dt.itemsize > 1 else dt).reshape(v['shape'])
+            if dt.itemsize > 1 and not (big and raw_big):
+                arr = arr.byteswap(inplace=True).view(dt)        # one pass, no second array
+            return arr
+
+        big = [v for v in hdr['vars'] if v['nbytes'] * (hdr['numrecs'] if v['record'] else 1) >= BIG_VARIABLE]
+        data = {}
+        if len(big) > 1 and threads > 1:
+            with ThreadPoolExecutor(max_workers=min(threads, len(big))) as pool:
+                for v, arr in zip(big, pool.map(read, big)):
+                    data[v['name']] = arr
+        for v in hdr['vars']:
+            if v['name'] not in data:
+                data[v['name']] = read(v)
+    finally:
+        os.close(fd)
+    ds = Dataset(attrs=hdr['attrs'])
+    coords = {}
+    for v in hdr['vars']:
+        if v['dims'] == (v['name'],):
+            arr = data[v['name']]
+            if decode_times and 'since' in str(v['attrs'].get('units', '')):
+                arr = decode_cf_time(arr, v['attrs']['units'], v['attrs'].get('calendar', 'standard'))
+                data[v['name']] = arr
+            coords[v['name']] = arr
+    for v in hdr['vars']:
+        ds.variables[v['name']] = Field(data[v['name']], v['dims'], {d: coords[d] for d in v['dims'] if d in coords},
+                                        v['attrs'], v['name'])
+    return ds
+
+
+def _open_dataset_scipy(path, decode_times=True, threads=4):
+    """The reader of the first version: scipy.io.netcdf_file over a memory map, every variable converted to a
+    native-endian copy."""
     from concurrent.futures import ThreadPoolExecutor
     try:
         nc = netcdf_file(path, 'r', mmap=True)
@@ -187,7 +369,7 @@ def open_dataset(path, decode_times=True, threads=4):
             native = src.dtype.newbyteorder('=') if src.dtype.byteorder in ('>', '<') else src.dtype
             return np.array(src, dtype=native, copy=True, order='C'), tuple(var.dimensions), _attrs(var)
 
-        big = [n for n in names if nc.variables[n].data.nbytes >= (16 << 20)]
+        big = [n for n in names if nc.variables[n].data.nbytes >= BIG_VARIABLE]
         raw = {}
         if len(big) > 1 and threads > 1:
             with ThreadPoolExecutor(max_workers=min(threads, len(big))) as pool:
@@ -255,18 +437,20 @@ def _nc_atts(attrs):
     return out
 
 
-def to_netcdf(ds, path, threads=4):
+def to_netcdf(ds, path, threads=None):
     """Write a Dataset as NetCDF-3 64-bit-offset (`.to_netcdf(path, mode='w')`, step_03:378).
 
     Native writer (the classic format is a header + fixed-size big-endian arrays): every variable
-    is byte-swapped in one pass and written with `os.pwrite` at its offset, large variables
-    concurrently - scipy's writer makes three copies of every array under the GIL and was the
+    is byte-swapped in one pass (not at all if it is already big-endian) and written with `os.pwrite`
+    at its offset, large variables in 64 MiB pieces on `threads` threads - scipy's writer makes three copies of every array under the GIL and was the
     bottleneck of the whole command line (1.06 s per 2.3 GB file; PGW_NC_WRITER=scipy selects it)."""
     import os
     import struct
     from concurrent.futures import ThreadPoolExecutor
     if os.environ.get('PGW_NC_WRITER') == 'scipy':
         return _to_netcdf_scipy(ds, path)
+    if threads is None:
+        threads = int(os.environ.get('PGW_NC_WRITE_THREADS', '8'))
     dims = {}
     for f in ds.variables.values():
         for d, n in zip(f.dims, f.shape):
@@ -327,32 +511,36 @@ def to_netcdf(ds, path, threads=4):
         os.ftruncate(fd, off)
         os.pwrite(fd, hdr, 0)
         CH = 64 << 20                                            # swap + write in 64 MiB pieces
+        flats = [np.ascontiguousarray(sp['data']).reshape(-1) for sp in specs]
 
-        def write_var(i):
-            sp, b = specs[i], begins[i]
-            flat = np.ascontiguousarray(sp['data']).reshape(-1)
-            be = flat.dtype.newbyteorder('>')
-            step = max(CH // max(flat.dtype.itemsize, 1), 1)
-            pos = b
-            for s0 in range(0, flat.size, step):
-                chunk = flat[s0:s0 + step].astype(be)              # one pass: copy + byte swap
-                mv = memoryview(chunk).cast('B')
-                while len(mv):
-                    n = os.pwrite(fd, mv, pos)
-                    pos += n
-                    mv = mv[n:]
+        def write_piece(task):
+            i, s0, s1 = task
+            flat = flats[i]
+            # one pass: copy + byte swap; no copy at all if the data are already big-endian (raw I/O path)
+            chunk = flat[s0:s1].astype(flat.dtype.newbyteorder('>'), copy=False)
+            mv = memoryview(chunk).cast('B')
+            pos = begins[i] + s0 * flat.dtype.itemsize
+            while len(mv):
+                n = os.pwrite(fd, mv, pos)
+                pos += n
+                mv = mv[n:]
             # padding bytes are already zero (ftruncate)
 
-        big = [i for i, sp in enumerate(specs) if sp['nbytes'] >= (16 << 20)]
-        if len(big) > 1 and threads > 1:
-            with ThreadPoolExecutor(max_workers=min(threads, len(big))) as pool:
-                list(pool.map(write_var, big))
+        tasks, small = [], []
+        for i, sp in enumerate(specs):
+            if sp['nbytes'] >= BIG_VARIABLE:
+                step = max(CH // max(flats[i].dtype.itemsize, 1), 1)
+                tasks += [(i, s0, min(s0 + step, flats[i].size)) for s0 in range(0, flats[i].size, step)]
+            elif flats[i].size:
+                small.append((i, 0, flats[i].size))
+        if len(tasks) > 1 and threads > 1:
+            with ThreadPoolExecutor(max_workers=min(threads, len(tasks))) as pool:
+                list(pool.map(write_piece, tasks))
         else:
-            for i in big:
-                write_var(i)
-        for i in range(len(specs)):
-            if i not in big:
-                write_var(i)
+            for t in tasks:
+                write_piece(t)
+        for t in small:
+            write_piece(t)
     finally:
         os.close(fd)
 

@@ -362,6 +362,24 @@ def load_delta_set(ctx, delta_input_dir, dtype):
     return dset
 
 
+_POOLS = {}
+_BIG_OUT = ('T', 'QV', 'U', 'V')
+
+
+def _io_raw():
+    """PGW_IO_RAW=0 converts the byte order of the 4-D fields on the host (first version of the drivers);
+    default: the file's big-endian bytes go to the GPU as they are, through pinned buffers, and come back
+    big-endian, so no host pass touches a field between `pread` and `pwrite`."""
+    return os.environ.get('PGW_IO_RAW', '1') != '0'
+
+
+def _pinned_pool(ctx):
+    from .device import PinnedPool
+    if id(ctx) not in _POOLS:
+        _POOLS[id(ctx)] = PinnedPool(ctx)
+    return _POOLS[id(ctx)]
+
+
 def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt,
                 ignore_top_pressure_error, debug_mode=None):
     """Stage 1 (host, I/O): read one ERA5 file and lay its fields out as C-order host arrays."""
@@ -371,15 +389,33 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
                                   'the reference and not part of the MI355X hot path')
     if S.i_debug >= 0:
         print('Start working on input file {}'.format(inp_era_file_path))
-    era_file = ncio.open_dataset(inp_era_file_path, decode_times=False)      # step_03:60
+    raw = _io_raw()
+    pinned = []
+    alloc = None
+    if raw:
+        pool = _pinned_pool(default_context())
+
+        def alloc(nbytes):
+            buf = pool.acquire(nbytes)
+            pinned.append(buf)
+            return buf
+    try:
+        era_file = ncio.open_dataset(inp_era_file_path, decode_times=False, raw_big=raw, alloc=alloc)   # step_03:60
+    except BaseException:
+        for b_ in pinned:
+            pool.release(b_)
+        raise
     vm = S.var_name_map
-    dtype = np.dtype('float64') if era_file[vm['ta']].dtype == np.float64 else np.dtype('float32')
+    dtype = np.dtype('float64') if era_file[vm['ta']].dtype.itemsize == 8 else np.dtype('float32')
     dims4 = (S.TIME_ERA, S.LEV_ERA, S.LAT_ERA, S.LON_ERA)
     dims3 = (S.TIME_ERA, S.LAT_ERA, S.LON_ERA)
     dims_so = (S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA)
 
     def get(name, dims):
-        return np.ascontiguousarray(era_file[name].transpose(*dims).values, dtype=dtype)
+        v = era_file[name].transpose(*dims).values
+        if (not v.dtype.isnative) and v.dtype.kind == 'f' and v.dtype.itemsize == dtype.itemsize and v.flags.c_contiguous:
+            return v                                                         # file byte order; converted on the GPU
+        return np.ascontiguousarray(v, dtype=dtype)
 
     era = dict(PS=get(vm['ps'], dims3), FIS=get(vm['zgs'], dims3), T=get(vm['ta'], dims4), QV=get(vm['hus'], dims4),
                U=get(vm['ua'], dims4), V=get(vm['va'], dims4), T_SKIN=get(vm['ts'], dims3),
@@ -391,7 +427,7 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
         coeffs['bkm'] = np.asarray(era_file['bkm'].values, dtype=np.float64)
     return dict(era_file=era_file, era=era, coeffs=coeffs, dtype=dtype, out_path=out_era_file_path,
                 delta_input_dir=delta_input_dir, era_step_dt=era_step_dt, ignore_top=ignore_top_pressure_error,
-                dims=dict(d3=dims3, d4=dims4, so=dims_so))
+                dims=dict(d3=dims3, d4=dims4, so=dims_so), pinned=pinned)
 
 
 _DEVICE_BUFFERS = {}
@@ -400,6 +436,7 @@ _DEVICE_BUFFERS = {}
 def _stage_compute(item):
     """Stage 2 (GPU): upload, one pgw_step03_file call, download.  Device buffers of a given
     shape/dtype are reused from file to file."""
+    from . import ncio
     ctx = default_context()
     dtype = item['dtype']
     deltas = load_delta_set(ctx, item['delta_input_dir'], dtype)
@@ -408,13 +445,39 @@ def _stage_compute(item):
     for k, v in item['era'].items():
         if k not in bufs['inp']:
             bufs['inp'][k] = ctx.empty(v.shape, dtype)
-        bufs['inp'][k].copy_from(v)
+        bufs['inp'][k].copy_from(v, sync=False)             # host arrays stay alive in `item` until the sync below
     run = process_file_device_reinterp if S.i_reinterp else process_file_device
     out, info = run(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
                     p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
-    item['result'] = {k: out[k].numpy() for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE')}
-    item['info'] = info
-    item['era'] = None                                  # release the host copies of the inputs
+    raw = _io_raw()
+    pool = _pinned_pool(ctx) if raw else None
+    result, pinned_out = {}, []
+    for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE'):
+        if raw and k in _BIG_OUT and out[k].nbytes >= ncio.BIG_VARIABLE:
+            hb = pool.acquire(out[k].nbytes)
+            pinned_out.append(hb)
+            result[k] = out[k].download_foreign(hb)         # big-endian on the device, DMA into pinned memory
+        else:
+            result[k] = out[k].numpy()
+    ctx.sync()
+    item['result'], item['info'] = result, info
+    item['era'] = None                                      # release the host copies of the inputs
+    # the four replaced 4-D variables leave the dataset now, so their pinned input buffers can be recycled
+    # before the writer gets to this file
+    era_file, vm = item['era_file'], S.var_name_map
+    if pool is not None:
+        for k in _BIG_OUT:
+            old = era_file[vm[dict(T='ta', QV='hus', U='ua', V='va')[k]]]
+            base = old.values
+            old.values = np.empty((0,) * base.ndim, dtype=base.dtype)
+            keep = []
+            for b_ in item['pinned']:
+                if b_.ctypes.data == base.ctypes.data:
+                    pool.release(b_)
+                else:
+                    keep.append(b_)
+            item['pinned'] = keep
+    item['pinned_out'] = pinned_out
     if S.i_debug >= 2:
         for it, err in enumerate(info['max_err']):
             print('### iteration {:03d}, phi max error: {}'.format(it + 1, err))
@@ -428,10 +491,19 @@ def _stage_store(item):
     era_file, vm, d = item['era_file'], S.var_name_map, item['dims']
     names = dict(PS=(vm['ps'], d['d3']), T=(vm['ta'], d['d4']), QV=(vm['hus'], d['d4']), U=(vm['ua'], d['d4']),
                  V=(vm['va'], d['d4']), T_SKIN=(vm['ts'], d['d3']), T_SO=(vm['st'], d['so']), FR_SEA_ICE=(vm['sic'], d['d3']))
-    for key, (name, dims) in names.items():
-        old = era_file[name]
-        era_file[name] = ncio.Field(item['result'][key], dims, {k: old.coords[k] for k in dims if k in old.coords}, old.attrs)
-    ncio.to_netcdf(era_file, item['out_path'])
+    try:
+        for key, (name, dims) in names.items():
+            old = era_file[name]
+            era_file[name] = ncio.Field(item['result'][key], dims, {k: old.coords[k] for k in dims if k in old.coords}, old.attrs)
+        ncio.to_netcdf(era_file, item['out_path'])
+    finally:
+        bufs = item.get('pinned', []) + item.get('pinned_out', [])
+        if bufs:
+            pool = _pinned_pool(default_context())
+            item['result'] = None
+            for b_ in bufs:
+                pool.release(b_)
+            item['pinned'], item['pinned_out'] = [], []
     if S.i_debug >= 1:
         print('Done. Saved to file {}.'.format(item['out_path']))
     return item['info']['n_iter']

@@ -144,3 +144,23 @@ def test_step03_cli_two_worker_ranks(files):
         b = ncio.open_dataset(os.path.join(serial, name), decode_times=False)
         for v in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
             np.testing.assert_array_equal(a[v].values, b[v].values, err_msg=v)
+
+
+def test_step03_cli_raw_io_path_is_byte_identical(files, monkeypatch):
+    """The driver's default I/O path (file bytes pread into pinned buffers, uploaded big-endian, byte order
+    converted on the GPU both ways) against PGW_IO_RAW=0 (byte order converted on the host): identical output
+    files, and the pinned buffers all return to the pool."""
+    from pgw4era5_amd import step_03_apply_to_era as s3, ncio
+    from pgw4era5_amd.device import default_context
+    root, cases = files
+    monkeypatch.setattr(ncio, 'BIG_VARIABLE', 1024)                      # the 6 x 8 x 12 test fields count as large
+    args = ['-i', str(root / 'era'), '-d', str(root / 'deltas'), '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '1', '-t']
+    n_raw = s3._cli(args + ['-o', str(root / 'out_raw')])
+    pool = s3._pinned_pool(default_context())
+    assert pool.allocated > 0 and sum(len(v) for v in pool._free.values()) == len(pool._owned)
+    monkeypatch.setenv('PGW_IO_RAW', '0')
+    n_host = s3._cli(args + ['-o', str(root / 'out_host')])
+    assert n_raw == n_host
+    for c in cases:
+        name = 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])
+        assert open(root / 'out_raw' / name, 'rb').read() == open(root / 'out_host' / name, 'rb').read()

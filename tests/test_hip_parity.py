@@ -601,3 +601,35 @@ def test_kernel_variants_are_bit_identical(monkeypatch, env):
     assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
     for k in ['PS', 'T', 'QV', 'U', 'V', 'RELHUM_pgw']:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+# ------------------------------------------------------------------ byte order conversion (NetCDF classic is big-endian)
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('n', [1, 3, 4, 1023, 65536 + 5])
+def test_byteswap_matches_numpy(dtype, n):
+    import ctypes as C
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(n)
+    x = rng.normal(size=n).astype(dtype)
+    x[0] = np.nan
+    d = ctx.to_device(x)
+    out = ctx.empty((n,), dtype)
+    ctx._check(ctx.lib.pgw_byteswap(ctx.handle, x.itemsize, n, d.ptr, out.ptr))
+    np.testing.assert_array_equal(out.numpy().view(np.uint8), x.byteswap().view(np.uint8))
+    ctx._check(ctx.lib.pgw_byteswap(ctx.handle, x.itemsize, n, out.ptr, out.ptr))               # in place, back again
+    np.testing.assert_array_equal(out.numpy().view(np.uint8), x.view(np.uint8))
+    if n > 1:                                                                                     # element-aligned, not 16 B aligned
+        ctx._check(ctx.lib.pgw_byteswap(ctx.handle, x.itemsize, n - 1, d.ptr + x.itemsize, out.ptr + x.itemsize))
+        np.testing.assert_array_equal(out.numpy()[1:].view(np.uint8), x[1:].byteswap().view(np.uint8))
+    # DeviceArray.copy_from of an array in the file's byte order, download_foreign back
+    be = x.astype(x.dtype.newbyteorder('>'))
+    d2 = ctx.empty((n,), dtype).copy_from(be)
+    np.testing.assert_array_equal(d2.numpy().view(np.uint8), x.view(np.uint8))
+    host = np.zeros(d2.nbytes + 3, dtype=np.uint8)
+    back = d2.download_foreign(host)
+    ctx.sync()
+    assert back.dtype == be.dtype
+    np.testing.assert_array_equal(back.view(np.uint8), be.view(np.uint8))
+    with pytest.raises(ValueError):
+        ctx._check(ctx.lib.pgw_byteswap(ctx.handle, 2, n, d.ptr, out.ptr))

@@ -40,6 +40,62 @@ def test_ncio_roundtrip_and_labels(tmp_path):
         ncio.open_dataset(str(tmp_path / 'b.nc'))
 
 
+def test_native_reader_matches_scipy_reader(tmp_path, monkeypatch):
+    """The header parser / pread reader against scipy.io.netcdf_file on files scipy wrote: classic and
+    64-bit-offset, fixed and record variables (one and several, odd sizes -> padding), attributes of every
+    type; and the raw mode that leaves large variables in the file's byte order."""
+    from scipy.io import netcdf_file
+    from pgw4era5_amd import ncio
+    rng = np.random.default_rng(3)
+    for version in (1, 2):
+        for nrecvars in (1, 2):
+            p = str(tmp_path / ('v%d_%d.nc' % (version, nrecvars)))
+            nc = netcdf_file(p, 'w', version=version)
+            nc.title = 'demo'; nc.scale = np.float32(2.5); nc.ids = np.array([1, 2, 3], dtype=np.int32)
+            nc.createDimension('time', None); nc.createDimension('x', 5); nc.createDimension('y', 3)
+            t = nc.createVariable('time', 'd', ('time',)); t.units = 'hours since 2000-01-01 00:00:00'
+            a = nc.createVariable('a', 'h', ('time', 'x'))                     # 10 bytes per record: padded unless alone
+            a.missing_value = np.int16(-9)
+            fx = nc.createVariable('fixed', 'f', ('y', 'x')); fx.units = 'K'
+            if nrecvars == 2:
+                b = nc.createVariable('b', 'f', ('time', 'y', 'x'))
+                b[:] = rng.normal(size=(4, 3, 5)).astype('f4')
+            t[:] = np.arange(4.0); a[:] = rng.integers(-100, 100, size=(4, 5)); fx[:] = rng.normal(size=(3, 5))
+            nc.close()
+            mine = ncio.open_dataset(p, decode_times=False)
+            monkeypatch.setenv('PGW_NC_READER', 'scipy')
+            ref = ncio.open_dataset(p, decode_times=False)
+            monkeypatch.delenv('PGW_NC_READER')
+            assert list(mine.variables) == list(ref.variables)
+            assert mine.attrs['title'] == 'demo' and mine.attrs['scale'] == np.float32(2.5)
+            np.testing.assert_array_equal(mine.attrs['ids'], [1, 2, 3])
+            for k in ref.variables:
+                assert mine[k].dims == ref[k].dims and mine[k].values.dtype == ref[k].values.dtype, k
+                np.testing.assert_array_equal(mine[k].values, ref[k].values, err_msg=k)
+                assert set(mine[k].attrs) == set(ref[k].attrs)
+            assert mine['a'].attrs['missing_value'] == -9
+            dec = ncio.open_dataset(p)
+            assert dec['time'].values[1] == np.datetime64('2000-01-01T01:00:00')
+    # raw mode: variables above the threshold stay big-endian in caller-supplied buffers, the writer takes them as is
+    monkeypatch.setattr(ncio, 'BIG_VARIABLE', 40)
+    handed = []
+
+    def alloc(n):
+        handed.append(np.zeros(n + 7, dtype=np.uint8))
+        return handed[-1]
+    raw = ncio.open_dataset(p, decode_times=False, raw_big=True, alloc=alloc)
+    assert raw['b'].values.dtype == np.dtype('>f4') and raw['fixed'].values.dtype == np.dtype('>f4')
+    assert raw['a'].values.dtype == np.dtype('>i2') and raw['time'].values.dtype.isnative     # 40 bytes: big; time (32) converted
+    assert len(handed) == 3 and raw['b'].values.ctypes.data == handed[[i for i, h in enumerate(handed) if h.nbytes == 247][0]].ctypes.data
+    np.testing.assert_array_equal(raw['b'].values, mine['b'].values)
+    ncio.to_netcdf(raw, str(tmp_path / 'raw_out.nc'))
+    ncio.to_netcdf(mine, str(tmp_path / 'native_out.nc'))
+    assert open(tmp_path / 'raw_out.nc', 'rb').read() == open(tmp_path / 'native_out.nc', 'rb').read()
+    with pytest.raises(IOError):
+        open(tmp_path / 'trunc.nc', 'wb').write(open(p, 'rb').read()[:40])
+        ncio.open_dataset(str(tmp_path / 'trunc.nc'))
+
+
 def test_decode_cf_time_calendars():
     from pgw4era5_amd.ncio import decode_cf_time
     got = decode_cf_time([0, 31, 59.5], 'days since 1850-01-01 00:00:00', 'proleptic_gregorian')

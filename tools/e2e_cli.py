@@ -44,9 +44,21 @@ def main():
     t0 = time.time()
     s3.load_delta_set(s3.default_context(), os.path.join(a.dir, 'deltas'), np.float32)      # once per run
     t_deltas = time.time() - t0
+    done = []
+    load, compute, store = s3.pgw_for_era5.stages
+
+    def store_logged(item):
+        out = store(item)
+        done.append(time.time())
+        return out
+    s3.pgw_for_era5.stages = (load, compute, store_logged)
     t0 = time.time()
     n_iter = s3._cli(argv)
     t_pipe = time.time() - t0
+    s3.pgw_for_era5.stages = (load, compute, store)
+    done.sort()
+    half = len(done) // 2                 # second half of the run: pinned buffers allocated, pipeline full
+    steady = (done[-1] - done[half - 1]) / (len(done) - half) if half >= 1 and len(done) > half else None
     # serial stages, timed individually on the first file
     kw = dict(inp_era_file_path=os.path.join(a.dir, 'era', S.era5_file_name_base.format(first)),
               out_era_file_path=os.path.join(a.dir, 'out', 'serial.nc'), delta_input_dir=os.path.join(a.dir, 'deltas'),
@@ -56,9 +68,11 @@ def main():
     t0 = time.time(); s3._stage_store(item); t_store = time.time() - t0
     print(json.dumps(dict(files=a.files, file_GB=round(size / 1e9, 3), n_iter=n_iter,
                           setup_write_s=round(t_write, 1), delta_load_s=round(t_deltas, 2),
-                          pipelined_s_per_file=round(t_pipe / a.files, 2),
-                          serial_stage_s=dict(read=round(t_load, 2), upload_compute_download=round(t_comp, 2), write=round(t_store, 2)),
-                          files_per_hour_one_rank=round(3600.0 / (t_pipe / a.files), 1))))
+                          pipelined_s_per_file=round(t_pipe / a.files, 3),
+                          steady_state_s_per_file=None if steady is None else round(steady, 3),
+                          io_raw=os.environ.get('PGW_IO_RAW', '1') != '0',
+                          serial_stage_s=dict(read=round(t_load, 3), upload_compute_download=round(t_comp, 3), write=round(t_store, 3)),
+                          files_per_hour_one_rank=round(3600.0 / (steady or t_pipe / a.files), 1))))
     shutil.rmtree(a.dir, ignore_errors=True)
 
 
