@@ -297,6 +297,16 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
     out['regrid_one_var_12_months'] = dict(kernel_ms=round(ms / cnt, 3), wall_ms=round(wall * 1e3, 3), algo_GB=round(nbytes / 1e9, 3),
                                            GBps=round(nbytes / 1e9 / (ms / cnt / 1e3), 1))
     src.free()
+    # byte-order conversion of one 4-D field in place (the I/O path runs it on T, QV, U, V both ways)
+    ctx.profile(True); ctx.profile_reset()
+    for _ in range(5):
+        ctx._check(ctx.lib.pgw_byteswap(ctx.handle, s, era['U'].size, era['U'].ptr, era['U'].ptr))
+        ctx._check(ctx.lib.pgw_byteswap(ctx.handle, s, era['U'].size, era['U'].ptr, era['U'].ptr))
+    ctx.sync()
+    cnt, ms = ctx.profile_get('byteswap')
+    ctx.profile(False); ctx.profile_reset()
+    out['byteswap_one_field'] = dict(kernel_ms=round(ms / cnt, 4), algo_GB=round(2 * era['U'].nbytes / 1e9, 3),
+                                     GBps=round(2 * era['U'].nbytes / 1e9 / (ms / cnt / 1e3), 1))
     # PCIe-inclusive: pinned staging buffers, one stream (copies and kernels serialised; the overlapped
     # variant is bounded by the same PCIe time, which dominates)
     names = ('T', 'QV', 'U', 'V')
