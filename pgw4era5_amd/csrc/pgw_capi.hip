@@ -534,6 +534,13 @@ template <typename T, int MODE>
 static int launch_interp_mode(pgw_ctx *ctx, int ntime, int S, int N, long long ncol, const T *var, const T *sp,
                               const T *tp, T *out, int logp_in) {
     long long total = (long long)ntime * ncol;
+    const char *ev = getenv("PGW_INTERP_LDS");      // tuning knob: 1 = the LDS-staged variant (first version)
+    if (!(ev && ev[0] == '1')) {
+        Prof pr(ctx, PGW_K_INTERP_LOGP);
+        hipLaunchKernelGGL((k_interp_logp_stream<T, MODE>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                           ntime, S, N, ncol, var, sp, tp, out, logp_in, ctx->d_status);
+        return PGW_OK;
+    }
     size_t per_thread = (size_t)2 * S * sizeof(double);
     int tpb = (per_thread * 256 <= 64 * 1024) ? 256 : (per_thread * 128 <= 64 * 1024) ? 128 : 64;
     size_t lds = per_thread * tpb;

@@ -585,6 +585,106 @@ __global__ __launch_bounds__(TPB) void k_interp_logp(int ntime, int S, int N, lo
     }
 }
 
+// Streaming variant (default): nothing is staged.  A column keeps a window of its source profile in registers -
+// levels j-2, j-1, j (the scan position) and j+1, with the loads of level j+2 in flight - and moves it forward when
+// a target passes level j, so every source element is read exactly once, one scan step ahead of its use, and the
+// kernel runs at full occupancy instead of the 8 waves per CU the [level][thread] LDS tile allows at S = 19.
+// Selection rule, restart on a non-ascending / NaN target (re-reads the column from level 0; rare) and error
+// reporting are those of k_interp_logp.
+#ifndef PGW_INTERP_MINB
+#define PGW_INTERP_MINB 1
+#endif
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(int ntime, int S, int N, long long ncol,
+                                                              const T *__restrict__ var, const T *__restrict__ srcP,
+                                                              const T *__restrict__ trgP, T *__restrict__ out,
+                                                              int logp_in, DevStatus *st) {
+    long long flat = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (flat >= (long long)ntime * ncol) return;
+    long long t = flat / ncol, c = flat - t * ncol;
+    const T *pv = var + t * S * ncol + c;
+    const T *pp = srcP + t * S * ncol + c;
+    const T *pt = trgP + t * N * ncol + c;
+    T *po = out + t * N * ncol + c;
+    const double s_first = logp_in ? (double)pp[0] : pgw_log((double)pp[0]);                         // :470
+    {
+        double s_last = (double)pp[(long long)(S - 1) * ncol];
+        if (!logp_in) s_last = pgw_log(s_last);
+        if (s_last < s_first) { report(st, 10, flat); }              // :500-501
+        double x_first = (double)pt[0], x_last = (double)pt[(long long)(N - 1) * ncol];
+        if (!logp_in) { x_first = pgw_log(x_first); x_last = pgw_log(x_last); }
+        if (x_last < x_first) { report(st, 11, flat); }              // :502-503
+    }
+    // source window
+    int j;
+    double xmm = 0, ymm = 0, xm = 0, ym = 0, xj, yj, xn, yn, rx, ry;
+    auto reset = [&]() {
+        j = 0;
+        xj = s_first; yj = (double)pv[0];
+        xn = (double)pp[ncol]; yn = (double)pv[ncol];                // S >= 2
+        if (!logp_in) xn = pgw_log(xn);
+        const long long o = (long long)(2 < S ? 2 : S - 1) * ncol;
+        rx = (double)pp[o]; ry = (double)pv[o];
+    };
+    reset();
+    double xprev = -__builtin_inf();
+    constexpr int U = 4;            // chunks of 4 target levels: the next chunk's loads are in flight while this one is done
+    double nx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)(u < N ? u : N - 1) * ncol];
+    for (int l0 = 0; l0 < N; l0 += U) {
+        double cx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cx[u] = nx[u];
+        if (l0 + U < N) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u;
+            if (l < N) {
+                double x = cx[u];
+                if (!logp_in) x = pgw_log(x);                            // :471
+                if (__builtin_expect(!(x >= xprev), 0)) {                // restart (descending or NaN target)
+                    x = no_speculate(x);
+                    reset();
+                }
+                while (j < S && !(xj == x || xj > x)) {                  // first s with src[s] == x or src[s] > x
+                    xmm = xm; ymm = ym; xm = xj; ym = yj; xj = xn; yj = yn;
+                    xn = logp_in ? rx : pgw_log(rx); yn = ry;
+                    ++j;
+                    const long long o = (long long)(j + 2 < S ? j + 2 : S - 1) * ncol;
+                    rx = (double)pp[o]; ry = (double)pv[o];
+                }
+                bool extrap = false;
+                double x1, y1, x2, y2;
+                bool same;                                               // i1 == i2: take y1
+                if (j >= S) {                                            // above range            :554-561
+                    extrap = true;
+                    same = (MODE != 1);
+                    x1 = (MODE == 1) ? xmm : xm; y1 = (MODE == 1) ? ymm : ym; x2 = xm; y2 = ym;
+                } else if (xj == x) {                                    // exact                  :540-543
+                    same = true; x1 = x2 = xj; y1 = y2 = yj;
+                } else if (j == 0) {                                     // below range            :530-538
+                    extrap = true;
+                    same = (MODE != 1);
+                    x1 = xj; y1 = yj; x2 = xn; y2 = yn;
+                } else {                                                 // bracket                :545-548
+                    same = false; x1 = xm; y1 = ym; x2 = xj; y2 = yj;
+                }
+                double y;
+                if (extrap && MODE == 3) y = __builtin_nan("");          // :569-570
+                else if (same) y = y1;                                   // :572-573
+                else y = y1 + (x - x1) * (y2 - y1) / (x2 - x1);          // :575-578
+                if (MODE == 0 && extrap) report(st, 12, flat);           // :564-566
+                po[(long long)l * ncol] = (T)y;
+                xprev = (x == x) ? x : __builtin_inf();                  // after a NaN target restart
+            }
+        }
+    }
+}
+
 // =====================================================================================
 // a7  time lerp of load_delta                                   functions.py:288-292
 // =====================================================================================

@@ -148,6 +148,10 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     ctx.set_levels(coeffs['ak'], coeffs['bk'], coeffs.get('akm'), coeffs.get('bkm'))
     T, PS = era['T'], era['PS']
     nt, N, nlat, nlon = T.shape
+    if nt != 1:
+        # the deltas are time-interpolated to ONE instant (functions.py:288-296); with more than one time step in
+        # the file the reference fails in vert_interp_delta -> interp_logp_4d (functions.py:457-459)
+        raise ValueError('Time dimension of input files is inconsistent!')
     out = {} if out is None else out
 
     def buf(name, shape):
@@ -225,6 +229,8 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     ctx.set_levels(coeffs['ak'], coeffs['bk'], coeffs.get('akm'), coeffs.get('bkm'))
     T, QV, PS, FIS = era['T'], era['QV'], era['PS'], era['FIS']
     nt, N, nlat, nlon = T.shape
+    if nt != 1:
+        raise ValueError('Time dimension of input files is inconsistent!')      # functions.py:457-459
     ncol, n2 = nlat * nlon, nt * nlat * nlon
     out = {} if out is None else out
     f64 = np.dtype('float64')

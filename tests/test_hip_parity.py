@@ -184,6 +184,39 @@ def test_interp_logp_4d_vs_oracle(F, mode, S, N):
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize('variant', ['stream', 'lds'])
+@pytest.mark.parametrize('mode', ['linear', 'constant', 'nan'])
+def test_interp_logp_unsorted_targets_and_nans(F, monkeypatch, variant, mode):
+    """Targets that are not monotone inside a column (legal as long as first <= last: the reference scans the
+    source from the start for every target, functions.py:527-548), NaN targets and NaN source pressures; the
+    streaming kernel (default) and the LDS-staged one (PGW_INTERP_LDS=1) must give the same bits."""
+    rng = np.random.default_rng(77)
+    nt, S, N, nlat, nlon = 1, 11, 29, 4, 37
+    ps = np.sort(rng.uniform(100, 1e5, (nt, S, nlat, nlon)), axis=1)
+    pt = rng.uniform(50, 1.05e5, (nt, N, nlat, nlon))
+    pt[:, 0] = 60.0; pt[:, -1] = 1.04e5                      # first <= last everywhere, shuffled in between
+    pt[0, 5, 1, 2] = np.nan
+    pt[0, 6, 1, 2] = 300.0
+    ps[0, 4, 2, 3] = np.nan                                  # a NaN source level is never selected as upper bracket
+    pt[0, 1:, 3, 5] = ps[0, [0, 3, 10] * 9 + [10], 3, 5]     # exact hits incl. first / last source level
+    v = rng.normal(0, 3, ps.shape)
+    want = O.interp_logp_4d(v, ps, pt, mode)
+    if variant == 'lds':
+        monkeypatch.setenv('PGW_INTERP_LDS', '1')
+    got = F.interp_logp_4d(v, ps, pt, mode)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12, equal_nan=True)
+    monkeypatch.delenv('PGW_INTERP_LDS', raising=False)
+    np.testing.assert_array_equal(got, F.interp_logp_4d(v, ps, pt, mode))
+    # float32 storage, pre-computed logs (interp_1d_for_timelatlon signature)
+    buf = np.zeros(pt.shape)
+    ok = np.isfinite(ps).all(axis=1) & np.isfinite(pt).all(axis=1)
+    lps, lpt = np.log(np.where(ok[:, None], ps, 1.0)), np.log(np.where(ok[:, None], pt, 1.0))
+    F.interp_1d_for_timelatlon(v, lps, lpt, buf, nt, nlat, nlon, mode)
+    want2 = np.zeros(pt.shape)
+    O.interp_1d_for_timelatlon(v, lps, lpt, want2, nt, nlat, nlon, mode)
+    np.testing.assert_allclose(buf, want2, rtol=1e-12, atol=1e-13, equal_nan=True)
+
+
 def test_interp_shape_errors(F):
     a = np.ones((1, 3, 2, 2))
     with pytest.raises(ValueError) as e:
@@ -633,3 +666,35 @@ def test_byteswap_matches_numpy(dtype, n):
     np.testing.assert_array_equal(back.view(np.uint8), be.view(np.uint8))
     with pytest.raises(ValueError):
         ctx._check(ctx.lib.pgw_byteswap(ctx.handle, 2, n, d.ptr, out.ptr))
+
+
+def test_file_with_two_time_steps_fails_like_the_reference():
+    """The deltas are interpolated to one instant, so a file with two time steps fails in the reference at
+    functions.py:457-459 (oracle: same message); function-level calls with ntime > 1 are legal and must index the
+    time axis correctly."""
+    from pgw4era5_amd import step_03_apply_to_era as s3, functions as F
+    cs = [_case(5, 6, 12, seed=s) for s in (1, 2)]
+    era = dict(cs[0]['era'])
+    for k, v in era.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 3:
+            era[k] = np.concatenate([c['era'][k] for c in cs], axis=0)
+    c = cs[0]
+    for run in (O.pgw_for_era5_arrays, s3.pgw_for_era5_arrays):
+        with pytest.raises(ValueError) as e:
+            run(era, c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+        assert str(e.value) == 'Time dimension of input files is inconsistent!'
+    # function level, ntime = 2: every time slice equals the single-time result
+    pa_hl, pa = F.hybrid_pressure(era['ak'], era['bk'], era['PS'])
+    rh = F.specific_to_relative_humidity(era['QV'], pa, era['T'])
+    phi = F.integ_geopot(pa_hl, era['FIS'], era['T'], era['QV'], era['level1'], 30000.0)
+    src_p = np.broadcast_to(np.asarray(c['plev'])[::-1][None, :, None, None], (2, len(c['plev'])) + era['PS'].shape[1:]).copy()
+    var = np.random.default_rng(0).normal(size=src_p.shape)
+    itp = F.interp_logp_4d(var, src_p, pa, 'constant')
+    for t, ct in enumerate(cs):
+        e1 = ct['era']
+        hl1, pa1 = F.hybrid_pressure(e1['ak'], e1['bk'], e1['PS'])
+        np.testing.assert_array_equal(pa_hl[t:t + 1], hl1)
+        np.testing.assert_array_equal(rh[t:t + 1], F.specific_to_relative_humidity(e1['QV'], pa1, e1['T']))
+        np.testing.assert_array_equal(phi[t:t + 1], F.integ_geopot(hl1, e1['FIS'], e1['T'], e1['QV'], e1['level1'], 30000.0))
+        np.testing.assert_array_equal(itp[t:t + 1], F.interp_logp_4d(var[t:t + 1], src_p[t:t + 1], pa1, 'constant'))
+    np.testing.assert_allclose(phi, O.integ_geopot(pa_hl, era['FIS'], era['T'], era['QV'], era['level1'], 30000.0), rtol=1e-12)
