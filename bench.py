@@ -297,6 +297,22 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
     out['regrid_one_var_12_months'] = dict(kernel_ms=round(ms / cnt, 3), wall_ms=round(wall * 1e3, 3), algo_GB=round(nbytes / 1e9, 3),
                                            GBps=round(nbytes / 1e9 / (ms / cnt / 1e3), 1))
     src.free()
+    # step_02 smoothing: one daily 19-level delta on the 192x384 GCM grid (366 x 19 x 192 x 384), values irrelevant
+    lt, inner = 366, 19 * 192 * 384
+    cos_t, sin_t = F.harmonic_tables(lt)
+    d_in, d_out = ctx.empty((lt, inner), dt), ctx.empty((lt, inner), dt)
+    ctx._check(ctx.lib.pgw_memset(ctx.handle, d_in.ptr, 0x3f, d_in.nbytes))
+    dp = C.POINTER(C.c_double)
+    ctx.profile(True); ctx.profile_reset()
+    for _ in range(4):
+        ctx._check(ctx.lib.pgw_harmonic_smooth(ctx.handle, 1 if s == 8 else 0, lt, inner, cos_t.ctypes.data_as(dp),
+                                               sin_t.ctypes.data_as(dp), d_in.ptr, d_out.ptr))
+    ctx.sync()
+    cnt, ms = ctx.profile_get('harmonic')
+    ctx.profile(False); ctx.profile_reset()
+    out['harmonic_smooth_daily_19lev'] = dict(kernel_ms=round(ms / cnt, 3), algo_GB=round(2 * d_in.nbytes / 1e9, 3),
+                                              GBps=round(2 * d_in.nbytes / 1e9 / (ms / cnt / 1e3), 1))
+    d_in.free(); d_out.free()
     # byte-order conversion of one 4-D field in place (the I/O path runs it on T, QV, U, V both ways)
     ctx.profile(True); ctx.profile_reset()
     for _ in range(5):

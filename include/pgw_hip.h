@@ -61,7 +61,7 @@ enum pgw_kernel_id {
     PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
     PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
     PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13, PGW_K_QUAD_DELTA = 14,
-    PGW_K_BYTESWAP = 15, PGW_K_COUNT = 16
+    PGW_K_BYTESWAP = 15, PGW_K_HARMONIC = 16, PGW_K_COUNT = 17
 };
 
 /* ---------------------------------------------------------------- context ------------ */
@@ -299,6 +299,15 @@ int pgw_surface_update(pgw_ctx *ctx, int dtype, int ntime, long long ncol, int n
                        const void *sic, const void *dsic, const void *dtos, const void *dts,
                        const void *land, const void *ts_clim, const void *tskin, const void *tso,
                        void *sic_out, void *dts_comb_out, void *tskin_out, void *tso_out);
+
+/* Spectral smoothing of a daily annual cycle, step_02 `smoothing`: filter_data / harmonic_ac_analysis,
+ * functions.py:603-740.  in / out: (ntime, inner) C-order, inner = product of the non-time dimensions; every
+ * column's series is replaced by mean + its first three harmonics (Storch & Zwiers 12.19-12.23), all NaN if the
+ * series holds a NaN (:694-696).  cos_tab / sin_tab: host tables [3][ntime] of cos / sin(2*pi*i/ntime * t), t = 1..ntime,
+ * i = 1..3, evaluated by the caller as the reference does (:716, 727).  ntime < 8 -> PGW_ERR_ARG with the reference's
+ * message (:734-737); ntime <= 1365. */
+int pgw_harmonic_smooth(pgw_ctx *ctx, int dtype, int ntime, long long inner, const double *cos_tab,
+                        const double *sin_tab, const void *in, void *out);
 
 /* Byte-order conversion on the device: dst[i] = byte-reversed src[i] for n elements of 4 or 8 bytes (in place
  * allowed).  NetCDF classic files are big-endian (the reference reads / writes them through xarray,

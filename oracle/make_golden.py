@@ -8,6 +8,7 @@ succeeds; only functions that touch none of them are called.  Nothing of the ref
 (source or bytecode) is written anywhere: the outputs are inputs + expected values.
 
 usage:  python oracle/make_golden.py            (writes tests/golden/ref_leaf_vectors.npz)
+        python oracle/make_golden.py harmonic   (writes tests/golden/ref_harmonic_vectors.npz only)
 """
 import os
 import sys
@@ -160,5 +161,40 @@ def main():
     print('wrote', len(out), 'arrays;', meta)
 
 
+def harmonic():
+    """harmonic_ac_analysis (reference functions.py:672-740), the per-column kernel of the step_02 `smoothing`
+    sub-command: daily annual cycles of 365 / 366 / 360 days and the shortest legal series, float64 and float32
+    inputs (the reference keeps the dtype of the file for the mean), a series with a NaN."""
+    F = import_reference_functions()
+    rng = np.random.default_rng(20261005)
+    out, meta = {}, {}
+    for lt in (365, 366, 360, 8, 9):
+        t = np.arange(lt)
+        ts = np.stack([2.0 + 1.5 * np.sin(2 * np.pi * (t + rng.uniform(0, lt)) / lt) + 0.4 * np.cos(4 * np.pi * t / lt)
+                       + rng.normal(0, 0.6, lt) for _ in range(6)])
+        out['ts64_%d' % lt] = ts
+        out['sm64_%d' % lt] = np.stack([F.harmonic_ac_analysis(x.copy()) for x in ts])
+        ts32 = ts.astype(np.float32)
+        out['ts32_%d' % lt] = ts32
+        res = [F.harmonic_ac_analysis(x.copy()) for x in ts32]
+        meta['dtype32_%d' % lt] = str(res[0].dtype)
+        out['sm32_%d' % lt] = np.stack(res)
+    x = out['ts64_365'][0].copy(); x[17] = np.nan
+    out['nan_in'] = x
+    out['nan_out'] = F.harmonic_ac_analysis(x.copy())
+    try:
+        F.harmonic_ac_analysis(np.arange(7.0))
+        meta['short_series'] = None
+    except BaseException as e:       # the reference calls sys.exit(...) without importing sys -> NameError
+        meta['short_series'] = '%s: %s' % (type(e).__name__, e)
+    np.savez_compressed(os.path.join(OUT, 'ref_harmonic_vectors.npz'), **out)
+    with open(os.path.join(OUT, 'ref_harmonic_vectors.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(out), 'arrays;', meta)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'harmonic':
+        harmonic()
+    else:
+        main()

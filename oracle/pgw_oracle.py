@@ -781,3 +781,48 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt,
     out.update(PS=res['ps_pgw'], T=pgw['ta'], QV=res['hus_pgw'], U=pgw['ua'], V=pgw['va'],
                n_iter=res['n_iter'], max_err=res['max_err'], RELHUM_pgw=pgw['hur'])
     return out
+
+
+# =====================================================================================
+# step_02 `smoothing`: spectral smoothing of a daily annual cycle      functions.py:603-740
+# =====================================================================================
+def harmonic_tables(lt):
+    """cos / sin of the first three harmonics at t = 1..lt (functions.py:716, 727): [3][lt] each."""
+    import math
+    tv = np.arange(1, lt + 1, 1)
+    arg = [2. * math.pi * i / lt * tv for i in (1, 2, 3)]
+    return np.stack([np.cos(a) for a in arg]), np.stack([np.sin(a) for a in arg])
+
+
+def harmonic_ac_analysis(ts):
+    """functions.py:672-740: mean + first three harmonics of a series (Storch & Zwiers 12.19-12.23);
+    a series with a NaN comes back all NaN (:694-696).  The reference ends with `sys.exit(...)` for series shorter
+    than 8 steps (:734-737) - in fact a NameError, `sys` is not imported there; this restatement raises ValueError
+    with the intended text."""
+    ts = np.asarray(ts)
+    if np.isnan(ts).any():
+        return np.full_like(ts, np.nan)
+    lt = len(ts)
+    if not (3 < lt // 2):
+        raise ValueError('Whooops that should not be the case for a yearly timeseries! i (reconstruction grade) is '
+                         'larger than the number of timeseries elements / 2.')
+    mean = ts.mean()                                   # in the dtype of the series (float32 files: float32)
+    cos_t, sin_t = harmonic_tables(lt)
+    total = 0
+    for k in range(3):
+        a = 2. / lt * (ts.dot(cos_t[k]))               # :728-730
+        b = 2. / lt * (ts.dot(sin_t[k]))
+        total = total + (a * cos_t[k] + b * sin_t[k])  # :733, summed by the builtin sum() at :739
+    return total + mean
+
+
+def filter_data_array(diff):
+    """filter_data (functions.py:603-669) on an in-memory array (time, [level,] y, x): every column's series is
+    replaced by its smoothed version, in the array's own dtype."""
+    diff = np.array(diff, copy=True)
+    if diff.ndim not in (3, 4):
+        raise ValueError('Wrong dimensions of input file should be 3 or 4-D')
+    flat = diff.reshape(diff.shape[0], -1)
+    for c in range(flat.shape[1]):
+        flat[:, c] = harmonic_ac_analysis(flat[:, c])
+    return flat.reshape(diff.shape)

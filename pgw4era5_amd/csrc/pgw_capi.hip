@@ -1247,6 +1247,31 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
 
 extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx->last_levels_touched; }
 
+extern "C" int pgw_harmonic_smooth(pgw_ctx *ctx, int dtype, int ntime, long long inner, const double *cos_tab,
+                                   const double *sin_tab, const void *in, void *out) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, inner >= 1 && in && out && cos_tab && sin_tab, "bad argument");
+    // functions.py:724-737: the first three harmonics need 3 < floor(ntime / 2)
+    if (!(3 < ntime / 2))
+        return fail(ctx, PGW_ERR_ARG, "Whooops that should not be the case for a yearly timeseries! i (reconstruction grade) "
+                                      "is larger than the number of timeseries elements / 2.");
+    const size_t lds = sizeof(double) * 6 * (size_t)ntime;
+    NEED(ctx, lds <= 64 * 1024, "time series longer than 1365 steps are not supported");
+    void *tab = nullptr;
+    int rc = ws_get(ctx, 5, lds, &tab);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(tab, cos_tab, lds / 2, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync((char *)tab + lds / 2, sin_tab, lds / 2, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                  // the host tables may be freed after the call
+    {
+        Prof pr(ctx, PGW_K_HARMONIC);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_harmonic_smooth<T, 8>), dim3(nblocks(inner, BLOCK)), dim3(BLOCK), lds, ctx->stream,
+                                             ntime, inner, (const double *)tab, (const T *)in, (T *)out));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst) {
     NEED(ctx, elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 or 8");
     NEED(ctx, n >= 0 && (n == 0 || (src && dst)), "bad argument");

@@ -1564,6 +1564,55 @@ __global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long l
     }
 }
 
+// =====================================================================================
+// step_02 `smoothing`: filter_data / harmonic_ac_analysis          functions.py:603-740
+// in / out (ntime, inner): one thread per column (level, y, x flattened), lanes along x, so each time step of a
+// wave is one coalesced row segment.  Pass 1 streams the series once (NaN test, sum, three cos / sin projections),
+// pass 2 writes mean + the three harmonics.  cos / sin tables [3][ntime] come from the host (numpy, evaluated as
+// the reference does at :716, 727) and are staged in LDS; every lane reads the same entry (broadcast).
+// =====================================================================================
+template <typename T, int U>
+__global__ __launch_bounds__(BLOCK) void k_harmonic_smooth(int ntime, long long inner, const double *__restrict__ tabs,
+                                                           const T *__restrict__ in, T *__restrict__ out) {
+    extern __shared__ double s_tab[];                 // cos[3][ntime], sin[3][ntime]
+    for (int i = threadIdx.x; i < 6 * ntime; i += BLOCK) s_tab[i] = tabs[i];
+    __syncthreads();
+    const long long c = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= inner) return;
+    const double *c1 = s_tab, *c2 = s_tab + ntime, *c3 = s_tab + 2 * ntime;
+    const double *s1 = s_tab + 3 * ntime, *s2 = s_tab + 4 * ntime, *s3 = s_tab + 5 * ntime;
+    const T *pi = in + c;
+    double sum = 0, a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0;
+    bool nan = false;
+    for (int t0 = 0; t0 < ntime; t0 += U) {
+        double x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = (double)pi[(long long)(t0 + u < ntime ? t0 + u : ntime - 1) * inner];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            if (t < ntime) {
+                nan |= (x[u] != x[u]);                                   // :694
+                sum += x[u];                                             // :699
+                a1 += x[u] * c1[t]; b1 += x[u] * s1[t];                  // :728-730
+                a2 += x[u] * c2[t]; b2 += x[u] * s2[t];
+                a3 += x[u] * c3[t]; b3 += x[u] * s3[t];
+            }
+        }
+    }
+    const double lt = (double)ntime;
+    const double mean = sum / lt, f = 2. / lt;
+    a1 = f * a1; b1 = f * b1; a2 = f * a2; b2 = f * b2; a3 = f * a3; b3 = f * b3;
+    T *po = out + c;
+    for (int t = 0; t < ntime; ++t) {
+        double h1 = a1 * c1[t] + b1 * s1[t];                             // :733
+        double h2 = a2 * c2[t] + b2 * s2[t];
+        double h3 = a3 * c3[t] + b3 * s3[t];
+        double r = ((h1 + h2) + h3) + mean;                              // :739
+        po[(long long)t * inner] = (T)(nan ? __builtin_nan("") : r);     // :695-696
+    }
+}
+
 // Byte-order conversion of a field (NetCDF classic data are big-endian): every 4- or 8-byte element of `src` is
 // written byte-reversed to `dst` (in place allowed), 16 B per lane, grid-stride.  HBM-bound: 2 x n x W bytes.
 template <int W>

@@ -515,6 +515,73 @@ def regrid_lat_lon(ds_gcm, ds_era5, var_name, method='bilinear', i_use_xesmf=0):
     return out
 
 
+# ------------------------------------------------------------------------------- step_02 smoothing
+def harmonic_tables(lt):
+    """cos / sin(2 pi i / lt * t), t = 1..lt, i = 1..3, evaluated as the reference does (functions.py:716, 727)
+    so the table entries are the same doubles: ([3][lt], [3][lt])."""
+    import math
+    tv = np.arange(1, lt + 1, 1)
+    arg = [2. * math.pi * i / lt * tv for i in (1, 2, 3)]
+    return (np.ascontiguousarray(np.stack([np.cos(a) for a in arg])),
+            np.ascontiguousarray(np.stack([np.sin(a) for a in arg])))
+
+
+def smooth_annual_cycle(diff):
+    """Spectral smoothing of every column of a (time, [level,] y, x) array on the GPU (`pgw_harmonic_smooth`):
+    the array form of filter_data (reference functions.py:603-669).  Returns the kind of `diff` (host array, labelled
+    array or DeviceArray), same dtype."""
+    ctx = default_context()
+    r = _raw(diff)
+    if len(r.shape) not in (3, 4):
+        raise ValueError('Wrong dimensions of input file should be 3 or 4-D')          # :648
+    dtype = _common_dtype(diff)
+    lt = int(r.shape[0])
+    inner = int(np.prod(r.shape[1:], dtype=np.int64))
+    cos_t, sin_t = harmonic_tables(max(lt, 1))
+    d_in = _dev(ctx, diff, dtype)
+    d_out = ctx.empty(r.shape, dtype)
+    ctx._check(ctx.lib.pgw_harmonic_smooth(ctx.handle, dtype_tag(dtype), lt, inner, cos_t.ctypes.data_as(_lib._dp),
+                                           sin_t.ctypes.data_as(_lib._dp), d_in.ptr, d_out.ptr))
+    return _out(ctx, d_out, diff)
+
+
+def harmonic_ac_analysis(ts):
+    """Smoothed version of one series: mean + first three harmonics (reference functions.py:672-740); a series
+    holding a NaN comes back all NaN in its own dtype, otherwise float64 like the reference.  Series shorter than 8
+    steps: ValueError with the reference's text (the reference's `sys.exit` at :735 is a NameError, `sys` is not
+    imported there)."""
+    ts = np.asarray(ts)
+    if ts.ndim != 1:
+        raise ValueError('harmonic_ac_analysis expects a 1-D series')
+    if np.isnan(ts).any():
+        return np.full_like(ts, np.nan)
+    out = smooth_annual_cycle(np.ascontiguousarray(ts, dtype=np.float64).reshape(-1, 1, 1))
+    return out.reshape(-1)
+
+
+def filter_data(annualcycleraw, variablename_to_smooth, outputpath):
+    """File form (reference functions.py:603-669): read the variable, drop size-1 dimensions (`.squeeze()`), smooth
+    every column along the first dimension, write the variable with its coordinates to `outputpath`."""
+    from . import ncio
+    ds = ncio.open_dataset(annualcycleraw)
+    f = ds[variablename_to_smooth]
+    keep = [i for i, n in enumerate(f.shape) if n != 1]
+    vals = f.values.reshape([f.shape[i] for i in keep])
+    dims = tuple(f.dims[i] for i in keep)
+    print('Dimension that is assumed to be time dimension is called: ', dims[0] if dims else None)
+    print('shape of data: ', vals.shape)
+    if vals.dtype not in (np.float32, np.float64):
+        vals = vals.astype(np.float64)
+    res = smooth_annual_cycle(vals)
+    print('Done with smoothing')
+    out = ncio.Dataset(attrs={})
+    for d in dims:
+        if d in ds:
+            out[d] = ds[d]
+    out[variablename_to_smooth] = ncio.Field(res, dims, {d: f.coords[d] for d in dims if d in f.coords}, f.attrs)
+    ncio.to_netcdf(out, outputpath)
+
+
 def interp_wrapper(origin_grid, target_grid, var_name, i_use_xesmf=0,
                    nan_interp_kernel_radius=300000, nan_interp_sharpness=3):
     """Per-variable choice of the regridding scheme (reference functions.py:1062-1141).

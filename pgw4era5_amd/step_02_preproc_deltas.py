@@ -4,15 +4,16 @@ step_02: regrid GCM climate deltas (and HIST climatologies) to the ERA5 grid on 
 Command line of the reference's step_02_preproc_deltas.py (:27-87): positional
 {smoothing,regridding}, -i, -o, -e, -v.  For every variable both `{var}_historical.nc` and
 `{var}_delta.nc` are processed (:116-119).  `regridding` runs the bilinear lat-then-lon kernel
-(functions.regrid_lat_lon); `smoothing` (daily deltas, "not really recommended", reference
-README.md:34) and the tos/siconc point-cloud interpolation are outside this build.
+(functions.regrid_lat_lon); `smoothing` runs the annual-cycle filter for daily deltas
+(functions.filter_data, reference functions.py:603-740); the tos/siconc point-cloud interpolation
+is outside this build.
 """
 import argparse
 import os
 from pathlib import Path
 
 from . import ncio
-from .functions import interp_wrapper
+from .functions import filter_data, interp_wrapper
 from .settings import file_name_bases, i_use_xesmf_regridding, nan_interp_kernel_radius, nan_interp_sharpness
 
 DEFAULT_VARS = 'ta,hur,ua,va,zg,hurs,tas,ps,tos,ts,siconc'
@@ -33,15 +34,21 @@ def main(argv=None):
         raise ValueError('Output directory (-o) is required.')
     if args.processing_step == 'regridding' and args.era5_file_path is None:
         raise ValueError('era5_file_path is required for regridding step.')
-    if args.processing_step == 'smoothing':
-        raise NotImplementedError('annual-cycle smoothing of daily deltas (functions.py:606-740) is out of scope')
     Path(args.output_dir).mkdir(exist_ok=True, parents=True)
     var_names = args.var_names.split(',')
     print('Run {} for variable names {}.'.format(args.processing_step, var_names))
-    ds_era5 = ncio.open_dataset(args.era5_file_path, decode_times=False)
+    smoothing = args.processing_step == 'smoothing'
+    ds_era5 = None if smoothing else ncio.open_dataset(args.era5_file_path, decode_times=False)
     done = []
     for var_name in var_names:
         print(var_name)
+        if smoothing:                                        # step_02_preproc_deltas.py:129-132
+            for clim_period in ['HIST', 'SCEN-HIST']:
+                fname = file_name_bases[clim_period].format(var_name)
+                inp, out = os.path.join(args.input_dir, fname), os.path.join(args.output_dir, fname)
+                filter_data(inp, var_name, out)
+                done.append(out)
+            continue
         if var_name in ('tos', 'siconc'):
             interp_wrapper(None, ds_era5, var_name)      # raises: ocean-grid scheme is out of scope
         for clim_period in ['HIST', 'SCEN-HIST']:

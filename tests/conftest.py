@@ -22,3 +22,14 @@ def golden():
     with open(os.path.join(GOLDEN, 'ref_leaf_vectors.json')) as f:
         meta = json.load(f)
     return dict(z), meta
+
+
+@pytest.fixture(scope='session')
+def golden_harmonic():
+    """Outputs of the reference's harmonic_ac_analysis (oracle/make_golden.py harmonic)."""
+    import json
+    import numpy as np
+    z = np.load(os.path.join(GOLDEN, 'ref_harmonic_vectors.npz'), allow_pickle=False)
+    with open(os.path.join(GOLDEN, 'ref_harmonic_vectors.json')) as f:
+        meta = json.load(f)
+    return dict(z), meta

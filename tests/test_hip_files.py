@@ -164,3 +164,40 @@ def test_step03_cli_raw_io_path_is_byte_identical(files, monkeypatch):
     for c in cases:
         name = 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])
         assert open(root / 'out_raw' / name, 'rb').read() == open(root / 'out_host' / name, 'rb').read()
+
+
+def test_step02_cli_smoothing(tmp_path):
+    """`step_02 smoothing`: daily delta files in, smoothed files out (size-1 dimensions squeezed like the
+    reference's `.squeeze()`, coordinates kept), against the oracle."""
+    from pgw4era5_amd import step_02_preproc_deltas as s2, ncio
+    rng = np.random.default_rng(8)
+    inp, out = tmp_path / 'daily', tmp_path / 'smooth'
+    inp.mkdir()
+    t = np.arange(365.0)
+    lat, lon, plev = np.linspace(-60, 60, 5), np.arange(6) * 60.0, np.array([85000., 50000., 20000.])
+    data = {}
+    for name, fname in (('ta', 'ta_delta.nc'), ('ta', 'ta_historical.nc'), ('tas', 'tas_delta.nc'), ('tas', 'tas_historical.nc')):
+        ds = ncio.Dataset(attrs=dict(source='synthetic daily annual cycle'))
+        ds['time'] = ncio.Field(t, ('time',), attrs=dict(units='days since 1995-01-01 00:00:00', calendar='noleap'))
+        ds['lat'] = ncio.Field(lat, ('lat',)); ds['lon'] = ncio.Field(lon, ('lon',))
+        if name == 'ta':
+            ds['plev'] = ncio.Field(plev, ('plev',))
+            v = (2 + np.sin(2 * np.pi * t / 365)[:, None, None, None] + rng.normal(0, 0.5, (365, 3, 5, 6))).astype(np.float32)
+            ds[name] = ncio.Field(v, ('time', 'plev', 'lat', 'lon'), attrs=dict(units='K'))
+        else:
+            v = (1 + rng.normal(0, 0.5, (365, 1, 5, 6))).astype(np.float32)       # a size-1 height dimension
+            ds['height'] = ncio.Field(np.array([2.0]), ('height',))
+            ds[name] = ncio.Field(v, ('time', 'height', 'lat', 'lon'), attrs=dict(units='K'))
+        data[fname] = v
+        ncio.to_netcdf(ds, str(inp / fname))
+    done = s2.main(['smoothing', '-i', str(inp), '-o', str(out), '-v', 'ta,tas'])
+    assert len(done) == 4
+    for fname, v in data.items():
+        name = fname.split('_')[0]
+        res = ncio.open_dataset(str(out / fname))
+        sq = v.reshape([n for n in v.shape if n != 1])
+        assert res[name].shape == sq.shape and res[name].dtype == np.float32
+        assert res[name].dims == (('time', 'plev', 'lat', 'lon') if name == 'ta' else ('time', 'lat', 'lon'))
+        np.testing.assert_allclose(res[name].values, O.filter_data_array(sq), rtol=0, atol=2e-6 * np.abs(v).max())
+        np.testing.assert_array_equal(res['lat'].values, lat)
+        assert res[name].attrs['units'] == 'K'

@@ -698,3 +698,35 @@ def test_file_with_two_time_steps_fails_like_the_reference():
         np.testing.assert_array_equal(phi[t:t + 1], F.integ_geopot(hl1, e1['FIS'], e1['T'], e1['QV'], e1['level1'], 30000.0))
         np.testing.assert_array_equal(itp[t:t + 1], F.interp_logp_4d(var[t:t + 1], src_p[t:t + 1], pa1, 'constant'))
     np.testing.assert_allclose(phi, O.integ_geopot(pa_hl, era['FIS'], era['T'], era['QV'], era['level1'], 30000.0), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ step_02 smoothing (functions.py:603-740)
+def test_harmonic_smoothing_golden_and_oracle(F, golden_harmonic):
+    """pgw_harmonic_smooth against the reference's own outputs (golden vectors) and the oracle on 3-D / 4-D blocks.
+    Tolerances: fp64 series 1e-12 of the series' scale (summation order: sequential on the GPU, BLAS dot / pairwise
+    mean in numpy); float32 series 1e-6 of the scale - the reference forms the mean of a float32 series in float32
+    (numpy keeps the dtype), this build in fp64."""
+    g, meta = golden_harmonic
+    for lt in (365, 366, 360, 8, 9):
+        ts, want = g['ts64_%d' % lt], g['sm64_%d' % lt]
+        for x, w in zip(ts, want):
+            got = F.harmonic_ac_analysis(x)
+            assert got.dtype == np.float64
+            np.testing.assert_allclose(got, w, rtol=0, atol=1e-12 * np.abs(x).max())
+        cube = np.ascontiguousarray(g['ts32_%d' % lt].T.reshape(lt, 2, 3))                  # (time, y, x) float32
+        sm = F.smooth_annual_cycle(cube)
+        assert sm.dtype == np.float32 and sm.shape == cube.shape
+        np.testing.assert_allclose(sm.reshape(lt, 6).T, g['sm32_%d' % lt], rtol=0, atol=1e-6 * np.abs(cube).max())
+    out = F.harmonic_ac_analysis(g['nan_in'])
+    assert np.isnan(out).all() and out.shape == g['nan_in'].shape
+    with pytest.raises(ValueError) as e:
+        F.harmonic_ac_analysis(np.arange(7.0))
+    assert 'Whooops' in str(e.value)
+    with pytest.raises(ValueError):
+        F.smooth_annual_cycle(np.zeros((8, 3)))
+    rng = np.random.default_rng(5)
+    for shape in [(365, 3, 7, 11), (366, 5, 300), (8, 1, 1, 1)]:
+        x = rng.normal(1.0, 2.0, shape)
+        x[3, ..., 0] = np.nan                                   # NaN columns come back all NaN, the others untouched by them
+        got = F.smooth_annual_cycle(x)
+        np.testing.assert_allclose(got, O.filter_data_array(x), rtol=0, atol=1e-12 * 10, equal_nan=True)

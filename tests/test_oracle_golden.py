@@ -287,3 +287,29 @@ def test_integ_geopot_against_literal_column_loop():
             ks = min((k for k in range(n + 1) if d[k] == d[k]), key=lambda k: d[k])
             want = phi[ks] - (O.CON_RD * tv[ks - 1]) * (math.log(p_ref) - math.log(p[ks]))
             assert abs(got[0, j, i] - want) <= 1e-9 * abs(want)
+
+
+def test_harmonic_ac_analysis_golden(golden_harmonic):
+    """step_02 smoothing: the restatement reproduces the reference's outputs bit for bit (float64 and float32
+    series of 365 / 366 / 360 / 8 / 9 steps, NaN series); the array form equals the per-column form."""
+    g, meta = golden_harmonic
+    for lt in (365, 366, 360, 8, 9):
+        for k in ('64', '32'):
+            ts, want = g['ts%s_%d' % (k, lt)], g['sm%s_%d' % (k, lt)]
+            got = np.stack([O.harmonic_ac_analysis(x) for x in ts])
+            assert got.dtype == np.dtype(meta['dtype32_%d' % lt]) == np.float64
+            eq(got, want)
+    np.testing.assert_array_equal(O.harmonic_ac_analysis(g['nan_in']), g['nan_out'])
+    assert meta['short_series'].startswith('NameError')          # the reference's sys.exit without `import sys`
+    with pytest.raises(ValueError):
+        O.harmonic_ac_analysis(np.arange(7.0))
+    cube = np.moveaxis(g['ts32_365'].reshape(2, 3, 1, 365), -1, 0).copy()        # (time, level, y, x) float32
+    sm = O.filter_data_array(cube)
+    assert sm.dtype == np.float32 and sm.shape == cube.shape
+    eq(sm[:, 1, 2, 0], g['sm32_365'][5].astype(np.float32))
+    with pytest.raises(ValueError):
+        O.filter_data_array(np.zeros((8, 3)))
+    # a smooth series made of the mean and the first three harmonics only is a fixed point
+    t = np.arange(1, 366)
+    x = 1.5 + 0.7 * np.cos(2 * np.pi * t / 365) - 0.2 * np.sin(6 * np.pi * t / 365)
+    np.testing.assert_allclose(O.harmonic_ac_analysis(x), x, atol=1e-13)
