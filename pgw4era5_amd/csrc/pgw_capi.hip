@@ -22,6 +22,7 @@ struct pgw_ctx {
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     LoopState *h_loop = nullptr;       // pinned ring of 3 read-backs of the device loop state
     hipEvent_t loop_ev[3] = {nullptr, nullptr, nullptr};
+    LoopMail *mail = nullptr;          // coherent host mailbox polled by the loop (PGW_DEVICE_LOOP=3/4)
     std::string err;
     long long err_col = -1;
     DevStatus *d_status = nullptr;     // device
@@ -228,6 +229,7 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
         hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->h_loop, 3 * sizeof(LoopState)) != hipSuccess ||
+        hipHostMalloc(&c->mail, sizeof(LoopMail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[2], hipEventDisableTiming) != hipSuccess ||
@@ -260,6 +262,7 @@ extern "C" int pgw_ctx_destroy(pgw_ctx *ctx) {
     if (ctx->join_ev) hipEventDestroy(ctx->join_ev);
     for (int i = 0; i < 3; ++i) if (ctx->loop_ev[i]) hipEventDestroy(ctx->loop_ev[i]);
     if (ctx->h_loop) hipHostFree(ctx->h_loop);
+    if (ctx->mail) hipHostFree(ctx->mail);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return PGW_OK;
@@ -776,18 +779,39 @@ static int side_stream_env() {
     return (e && e[0] == '1') ? 1 : 0;
 }
 
+#ifndef PGW_LOOP_DEFAULT
+#define PGW_LOOP_DEFAULT 0
+#endif
 static int device_loop_env() {
     // Loop control (fixed p_ref), PGW_DEVICE_LOOP:
-    //   0 (default): the host reads max|err| after every pass before launching the next (the reference's flow
-    //      literally); 4.55 ms per 1440x721xL137 file;
-    //   2: one pass ahead - pass k+1 is enqueued before the host has read pass k; a device-side `done` flag turns
-    //      the single speculated pass after convergence into a no-op.  Measured 4.69 ms: the speculated launch and
-    //      the per-pass read-back copies + events cost more than the ~10 us round trips they hide;
+    //   0: the host reads max|err| after every pass (status copy + stream synchronisation) before launching the
+    //      next - the reference's flow literally;
+    //   4: the same flow, but the block that finishes a pass last writes the result to a coherent host mailbox and
+    //      the host polls it (no copy, no synchronisation per pass);
+    //   3: mailbox + one pass ahead: pass k+1 is enqueued before the host has seen pass k; a device-side `done`
+    //      flag turns the single speculated pass after convergence into a no-op;
+    //   2: one pass ahead through a pinned read-back ring (copy + event per pass; measured 4.69 vs 4.55 ms of mode 0);
     //   1: all max_n_iter passes enqueued back to back (measured slowest: 14 no-op launches per file).
     const char *e = getenv("PGW_DEVICE_LOOP");
-    if (e && e[0] == '1') return 1;
-    if (e && e[0] == '2') return 2;
-    return 0;
+    if (e && e[0] >= '0' && e[0] <= '4') return e[0] - '0';
+    return PGW_LOOP_DEFAULT;
+}
+
+// wait until the mailbox reports `want` finished passes; gives up when the stream has drained without the report
+static int poll_mail(pgw_ctx *ctx, unsigned int want) {
+    LoopMail *m = ctx->mail;
+    for (unsigned long long spins = 1;; ++spins) {
+        if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) >= want) return PGW_OK;
+        if ((spins & 0xFFFF) == 0) {
+            hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) >= want) return PGW_OK;
+                return fail(ctx, PGW_ERR_HIP, "surface-pressure loop: a pass finished without reporting to the host mailbox");
+            }
+            if (q != hipErrorNotReady) return fail(ctx, PGW_ERR_HIP, "surface-pressure loop: %s", hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 static int pair_staged_env() {
@@ -894,41 +918,62 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     }
     HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
 
-    if (!local && device_loop_env() == 2) {
-        // One pass ahead: pass k+1 is enqueued BEFORE the host has seen the result of pass k, so the GPU never
-        // idles for a host round trip.  Every pass first checks the device-side `done` flag (set by the last
-        // block of the pass that reached max|err| <= thresh) and returns at once if it is set, so the one
-        // speculated pass after convergence changes nothing.  The host follows one pass behind through a
-        // pinned read-back ring and applies the reference's control flow (step_03:189, 313-319) to what it reads.
+    if (!local && device_loop_env() >= 2) {
+        // Modes 2-4 (see device_loop_env): every pass first checks the device-side `done` flag (set by the last
+        // block of the pass that reached max|err| <= thresh) and returns at once if it is set, so a pass speculated
+        // beyond convergence changes nothing.  The host applies the reference's control flow (step_03:189, 313-319)
+        // to what it reads from the read-back ring (mode 2) or the polled mailbox (modes 3, 4).
+        const int mode = device_loop_env();
+        const bool mailbox = mode >= 3, speculate = mode <= 3;
         NEED(ctx, max_n_iter <= 32, "max_n_iter must be <= 32 for the device-assisted loop");
         void *lsv = nullptr;
         if ((rc = ws_get(ctx, 4, sizeof(LoopState), &lsv))) return rc;
         LoopState *ls = (LoopState *)lsv;
-        HIPCHK(ctx, hipMemsetAsync(ls, 0, sizeof(LoopState), ctx->stream));
+        LoopState init;
+        memset(&init, 0, sizeof(init));
+        if (mailbox) {
+            void *dmail = nullptr;
+            HIPCHK(ctx, hipHostGetDevicePointer(&dmail, ctx->mail, 0));
+            init.mail = (unsigned long long)(uintptr_t)dmail;
+            ctx->mail->done = 0;
+            __atomic_store_n(&ctx->mail->seq, 0u, __ATOMIC_RELEASE);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(ls, &init, sizeof(LoopState), hipMemcpyHostToDevice, ctx->stream));   // pageable: staged before return
         auto enqueue_pass = [&](int slot) -> int {
             launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
                         adj_factor, full_column, 1, ls, thresh);
-            HIPCHK(ctx, hipMemcpyAsync(&ctx->h_loop[slot], ls, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipEventRecord(ctx->loop_ev[slot], ctx->stream));
+            if (!mailbox) {
+                HIPCHK(ctx, hipMemcpyAsync(&ctx->h_loop[slot], ls, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(ctx, hipEventRecord(ctx->loop_ev[slot], ctx->stream));
+            }
             return PGW_OK;
         };
         if ((rc = enqueue_pass(0))) return rc;
         unsigned long long touched = 0;
         int passes = 0;
-        bool converged = false, too_many = false;
+        bool too_many = false;
         for (int k = 0;; ++k) {
-            if ((rc = enqueue_pass((k + 1) % 3))) return rc;                // speculative next pass
-            HIPCHK(ctx, hipEventSynchronize(ctx->loop_ev[k % 3]));
-            const LoopState &h = ctx->h_loop[k % 3];                        // state after pass k
+            if (speculate && (rc = enqueue_pass((k + 1) % 3))) return rc;   // the next pass, before pass k is known
+            int done;
+            double err_k;
+            unsigned long long lev_k;
+            if (mailbox) {
+                if ((rc = poll_mail(ctx, (unsigned int)(k + 1)))) return rc;
+                done = ctx->mail->done; err_k = ctx->mail->max_err[k & 31]; lev_k = ctx->mail->levels[k & 31];
+            } else {
+                HIPCHK(ctx, hipEventSynchronize(ctx->loop_ev[k % 3]));
+                const LoopState &h = ctx->h_loop[k % 3];                    // state after pass k
+                done = h.done; err_k = h.max_err[k & 31]; lev_k = h.levels[k & 31];
+            }
             passes = k + 1;
             if (k < 32) {
-                touched += h.levels[k];
-                if (max_err_hist && k < hist_len) max_err_hist[k] = h.max_err[k];
+                touched += lev_k;
+                if (max_err_hist && k < hist_len) max_err_hist[k] = err_k;
             }
             if (k + 2 > max_n_iter) { too_many = true; break; }            // it += 1 ; if it > max_n_iter: raise   :313-319
-            if (h.done) { converged = true; break; }                        // while phi_ref_max_error > thresh      :189
+            if (done) break;                                                // while phi_ref_max_error > thresh      :189
+            if (!speculate && (rc = enqueue_pass(0))) return rc;
         }
-        (void)converged;
         ctx->last_levels_touched = touched;
         if (n_iter) *n_iter = passes;
         if (!too_many && (ps_pgw || hus_pgw)) {

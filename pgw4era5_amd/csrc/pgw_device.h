@@ -38,6 +38,17 @@ struct LoopState {
     int pad;
     double max_err[32];
     unsigned long long levels[32];     // levels read per pass (bytes-moved accounting)
+    unsigned long long mail;           // address of a LoopMail in coherent host memory, or 0
+};
+
+// Host-visible mailbox of the loop (pinned, coherent host memory mapped into the device): the block that finishes a
+// pass last stores the pass result here and then publishes `seq` = passes finished with a system-scope release
+// store; the host polls `seq` instead of paying a copy + stream synchronisation per pass.
+struct LoopMail {
+    unsigned int seq;
+    int done;
+    double max_err[32];
+    unsigned long long levels[32];
 };
 
 template <typename T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };

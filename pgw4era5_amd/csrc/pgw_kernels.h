@@ -423,6 +423,13 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
                 atomicExch(&st->valid, 0ull);
                 atomicExch(&st->levels_touched, 0ull);
                 atomicExch(&ls->arrivals, 0u);
+                LoopMail *mail = (LoopMail *)ls->mail;
+                if (mail) {                                               // tell the polling host
+                    if (it < 32) { mail->max_err[it] = mx; mail->levels[it] = lev; }
+                    mail->done = !(mx > thresh) ? 1 : 0;
+                    __threadfence_system();
+                    __hip_atomic_store(&mail->seq, (unsigned int)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
     }

@@ -536,12 +536,14 @@ def test_reinterp_mode_vs_oracle(dtype):
     assert np.abs(base['T'] - got['T']).max() > 1e-6
 
 
-@pytest.mark.parametrize('mode', ['1', '2'])
+@pytest.mark.parametrize('mode', ['0', '1', '2', '3', '4'])
 def test_device_controlled_loop_matches_host_controlled(monkeypatch, mode):
-    """The three loop-control variants - default: the host reads max|err| before every launch (the
-    reference's flow literally); PGW_DEVICE_LOOP=2: one pass enqueued ahead of the host with a
-    device-side `done` flag; =1: all passes enqueued back to back - give bit-identical results, the
-    same iteration count and the same non-convergence error."""
+    """The loop-control variants (PGW_DEVICE_LOOP; pgw_capi.hip device_loop_env) - 0: the host reads max|err|
+    through a status copy + synchronisation before every launch (the reference's flow literally); 4: the same
+    flow with the result polled from a coherent host mailbox; 3: mailbox + one pass enqueued ahead with a
+    device-side `done` flag; 2: one pass ahead through a read-back ring; 1: all passes enqueued back to back -
+    give bit-identical results, the same iteration count, error history and non-convergence error as the
+    build's default."""
     from pgw4era5_amd import step_03_apply_to_era as s3
     c = _case(9, 16, 30, seed=41)
     a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
