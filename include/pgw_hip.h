@@ -319,6 +319,11 @@ int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, voi
  * pgw_log: fdlibm log kernel for positive normal finite x, ocml log otherwise); device fp64 arrays */
 int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out);
 
+/* diagnostic: out[i] = num[i] / den[i] through the shared-divisor path (pgw_device.h SharedDivisor: reciprocal once,
+ * three instructions per quotient) that the regridding and delta kernels use where many numerators share a divisor;
+ * device fp64 arrays.  Tests require the IEEE quotient bit for bit. */
+int pgw_test_shared_div(pgw_ctx *ctx, long long n, const double *num, const double *den, double *out);
+
 /* integrate_tos(tos_field, ts_field, land_frac, ice_frac)  functions.py:1145-1186, flat over n */
 int pgw_integrate_tos(pgw_ctx *ctx, int dtype, long long n, const void *tos, const void *ts,
                       const void *land, const void *ice, void *out);

@@ -1292,6 +1292,13 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
 
 extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx->last_levels_touched; }
 
+extern "C" int pgw_test_shared_div(pgw_ctx *ctx, long long n, const double *num, const double *den, double *out) {
+    NEED(ctx, n >= 1 && num && den && out, "bad argument");
+    hipLaunchKernelGGL(k_test_shared_div, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, num, den, out);
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 extern "C" int pgw_harmonic_smooth(pgw_ctx *ctx, int dtype, int ntime, long long inner, const double *cos_tab,
                                    const double *sin_tab, const void *in, void *out) {
     NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
@@ -1393,10 +1400,19 @@ extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, in
                                    nlat_s, nlon_s, (const T *)src, south_row, north_row, dpole);
             // z-slices: enough blocks to fill 256 CUs several times over even for small target grids
             long long xy = (long long)nblocks(nlon_t, BLOCK) * nlat_t;
-            long long want = (8192 + xy - 1) / xy;
+            const char *gzw = getenv("PGW_REGRID_BLOCKS");   // tuning knob: target number of blocks
+            long long want = ((gzw ? atoll(gzw) : 8192) + xy - 1) / xy;
             unsigned int gz = (unsigned int)(want < 1 ? 1 : (want > nfield ? nfield : want));
-            hipLaunchKernelGGL((k_regrid<T, 4>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                               nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+            const char *fu = getenv("PGW_REGRID_FU");     // tuning knob: planes per step
+            if (fu && fu[0] == '8')
+                hipLaunchKernelGGL((k_regrid<T, 8>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+            else if (fu && fu[0] == '2')
+                hipLaunchKernelGGL((k_regrid<T, 2>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+            else
+                hipLaunchKernelGGL((k_regrid<T, 4>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
         });
     }
     HIPCHK(ctx, hipGetLastError());

@@ -73,6 +73,29 @@ __device__ __forceinline__ void report(DevStatus *st, int code, long long col) {
     atomicCAS(&st->code, 0, code);
 }
 
+// ---- division by a value that many numerators share ---------------------------------------
+// The compiler expands an IEEE fp64 division into v_div_scale x2, v_rcp, two Newton steps on the reciprocal,
+// q = n*r, one residual correction (v_div_fmas) and v_div_fixup: 11 instructions.  When many numerators are
+// divided by the same d, the reciprocal part (v_rcp + 4 FMAs) is computed once and each quotient costs the last
+// three instructions.  The arithmetic is the compiler's own sequence, so quotients are bit-identical whenever
+// v_div_scale would not rescale (finite operands whose exponents are far from the denormal / overflow range -
+// true for every divisor this is used with: grid spacings and ln-pressure intervals); NaN numerators propagate,
+// a -0 numerator gives +0 (v_div_fixup would restore the sign; the value is the same).
+// Not for divisors that can be 0, infinite or denormal-scale.
+struct SharedDivisor {
+    double d, r;
+    __device__ __forceinline__ explicit SharedDivisor(double den) : d(den) {
+        double y = __builtin_amdgcn_rcp(den);
+        y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+        y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+        r = y;
+    }
+    __device__ __forceinline__ double divide(double n) const {
+        double q = n * r;
+        return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+    }
+};
+
 // ---- natural logarithm ------------------------------------------------------------------
 // Every kernel on the path takes one ln(p) per level and column, and with fp64 vector math at
 // half rate the generic ocml log (~65 instructions, double-double internals, denormal /

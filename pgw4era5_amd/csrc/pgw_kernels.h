@@ -1320,54 +1320,128 @@ struct RegridTables {
     const double *lon_dx, *lon_Dx;
 };
 
-// One thread owns one target (lat, lon) point and walks the fields (time x plev planes): the
-// index/weight tables are read once per thread and live in registers, the four source gathers of
-// consecutive lanes fall on ~16 neighbouring source columns (L1/L2 hits; one source plane is
-// 0.6 MB), and each plane's outputs are coalesced row segments.  FCH planes per thread per launch
-// slice (gridDim.z slices) keep >= 8 independent gathers in flight.
+// A block owns 256 consecutive target longitudes of one target latitude row and walks the fields (time x plev
+// planes).  All its points interpolate between the same two source rows, and 256 target longitudes of a 0.25 deg
+// grid fall on ~70 consecutive source columns, so per plane the block first does the LATITUDE pass once per needed
+// source column (coalesced loads of the two source rows; the values the reference's first interp1d produces at
+// those columns, :859) into LDS, and each thread then takes its two neighbours from LDS for the LONGITUDE pass
+// (:892) - instead of four uncoalesced 8-byte gathers per output, which kept the texture-address path, not HBM,
+// busy (2.4 TB/s).  Arithmetic per output value is unchanged: slope*(x_new-x_lo)+y_lo as scipy interp1d, twice.
+// Source columns are addressed relative to the first valid lane's lower neighbour, modulo nlon_s (periodic
+// wrap); a block whose points span more than REGRID_SPAN source columns (coarse or unsorted targets) gathers
+// directly like the first version.  FU planes per step; the next step's source loads are issued before this
+// step's stores.
+constexpr int REGRID_SPAN = BLOCK;       // one source column per thread
+
 template <typename T, int FU>
 __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, int nlon_s, int nlat_t, int nlon_t,
                                                   const T *__restrict__ src, RegridTables tb,
                                                   const double *__restrict__ pole, T *__restrict__ out) {
-    int i = blockIdx.x * BLOCK + threadIdx.x;       // target lon
-    int j = blockIdx.y;                             // target lat
-    if (i >= nlon_t) return;
+    __shared__ double s_y[FU][REGRID_SPAN];
+    __shared__ int s_first, s_span;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;       // target lon
+    const int j = blockIdx.y;                             // target lat
+    const bool active = i < nlon_t;
+    const int ii = active ? i : nlon_t - 1;
     const int jl = tb.lat_lo[j], jh = tb.lat_hi[j];
     const double ldx = tb.lat_dx[j], lDx = tb.lat_Dx[j];
-    const int il = tb.lon_lo[i], ih = tb.lon_hi[i];
-    const double odx = tb.lon_dx[i], oDx = tb.lon_Dx[i];
-    const bool oob = tb.lat_oob[j] || tb.lon_oob[i];
+    const int il = tb.lon_lo[ii], ih = tb.lon_hi[ii];
+    const double odx = tb.lon_dx[ii], oDx = tb.lon_Dx[ii];
+    const bool lat_oob = tb.lat_oob[j] != 0;
+    const bool oob = lat_oob || tb.lon_oob[ii];
+    const bool valid = active && !tb.lon_oob[ii];
     const long long plane_s = (long long)nlat_s * nlon_s, plane_t = (long long)nlat_t * nlon_t;
     const bool lo_pole = jl < 0 || jl >= nlat_s, hi_pole = jh < 0 || jh >= nlat_s;
-    const long long o_ll = (long long)(lo_pole ? 0 : jl) * nlon_s + il, o_lh = (long long)(lo_pole ? 0 : jl) * nlon_s + ih;
-    const long long o_hl = (long long)(hi_pole ? 0 : jh) * nlon_s + il, o_hh = (long long)(hi_pole ? 0 : jh) * nlon_s + ih;
+    const long long row_lo = (long long)(lo_pole ? 0 : jl) * nlon_s, row_hi = (long long)(hi_pole ? 0 : jh) * nlon_s;
     const int lo_which = jl < 0 ? 0 : 1, hi_which = jh < 0 ? 0 : 1;
+    // the two grid spacings divide every plane's differences: reciprocals once per thread (SharedDivisor)
+    const SharedDivisor by_lDx(lDx), by_oDx(oDx);
+    // source-column window of this block
+    if (threadIdx.x == 0) { s_first = BLOCK; s_span = 0; }
+    __syncthreads();
+    if (valid) atomicMin(&s_first, (int)threadIdx.x);
+    __syncthreads();
+    const int first = s_first;                            // BLOCK if the block has no valid point
+    int c0 = 0;
+    if (first < BLOCK) c0 = tb.lon_lo[blockIdx.x * BLOCK + first];
+    int rl = il - c0, rh = ih - c0;
+    if (rl < 0) rl += nlon_s;
+    if (rh < 0) rh += nlon_s;
+    if (valid) atomicMax(&s_span, (rl > rh ? rl : rh) + 1);
+    __syncthreads();
+    const int span = s_span;
+    const bool staged = !lat_oob && span <= REGRID_SPAN;
     // fields of this z-slice
     long long per = (nfield + gridDim.z - 1) / gridDim.z;
     long long f0 = (long long)blockIdx.z * per, f1 = f0 + per < nfield ? f0 + per : nfield;
-    T *po = out + (long long)j * nlon_t + i;
+    T *po = out + (long long)j * nlon_t + ii;
+    if (staged) {
+        // this thread's source column of the window (threads >= span idle in the latitude pass)
+        const bool loader = (int)threadIdx.x < span;
+        int col = c0 + (int)threadIdx.x;
+        if (col >= nlon_s) col -= nlon_s;
+        if (!loader) col = 0;
+        const int li = valid ? rl : 0, hi = valid ? rh : 0;
+        double v_lo[FU], v_hi[FU];
+        auto fetch = [&](long long f) {                    // the two source rows of FU planes at this thread's column
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                long long ff = (f + u < f1) ? f + u : f1 - 1;
+                const T *sp = src + ff * plane_s;
+                v_lo[u] = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[row_lo + col];
+                v_hi[u] = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[row_hi + col];
+            }
+        };
+        if (loader && f0 < f1) fetch(f0);
+        for (long long f = f0; f < f1; f += FU) {
+            if (loader) {
+#pragma unroll
+                for (int u = 0; u < FU; ++u) s_y[u][threadIdx.x] = by_lDx.divide(v_hi[u] - v_lo[u]) * ldx + v_lo[u];   // lat pass :859
+            }
+            __syncthreads();
+            if (loader && f + FU < f1) fetch(f + FU);      // next planes' loads fly during this group's stores
+            double ya[FU], yb[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) { ya[u] = s_y[u][li]; yb[u] = s_y[u][hi]; }
+            __syncthreads();                               // s_y is rewritten by the next group of planes
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < FU; ++u) {
+                    if (f + u < f1) {
+                        double r = oob ? __builtin_nan("") : by_oDx.divide(yb[u] - ya[u]) * odx + ya[u];   // lon pass :892
+                        po[(f + u) * plane_t] = (T)r;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // window wider than the tile (target coarser than the source, unsorted target longitudes) or latitude out of
+    // bounds: four direct gathers per point, like the first version of this kernel
+    const long long o_ll = row_lo + il, o_lh = row_lo + ih, o_hl = row_hi + il, o_hh = row_hi + ih;
     for (long long f = f0; f < f1; f += FU) {
-        double a_lo[FU], a_hi[FU], b_lo[FU], b_hi[FU];
+        double ya[FU], yb[FU];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             long long ff = (f + u < f1) ? f + u : f1 - 1;
-            const T *s = src + ff * plane_s;
-            a_lo[u] = lo_pole ? pole[ff * 2 + lo_which] : (double)s[o_ll];
-            b_lo[u] = lo_pole ? pole[ff * 2 + lo_which] : (double)s[o_lh];
-            a_hi[u] = hi_pole ? pole[ff * 2 + hi_which] : (double)s[o_hl];
-            b_hi[u] = hi_pole ? pole[ff * 2 + hi_which] : (double)s[o_hh];
+            const T *sp = src + ff * plane_s;
+            double a_lo = 0, b_lo = 0, a_hi = 0, b_hi = 0;
+            if (!oob) {
+                a_lo = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[o_ll];
+                b_lo = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[o_lh];
+                a_hi = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[o_hl];
+                b_hi = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[o_hh];
+            }
+            ya[u] = by_lDx.divide(a_hi - a_lo) * ldx + a_lo;                      // lat pass at the lower lon  :859
+            yb[u] = by_lDx.divide(b_hi - b_lo) * ldx + b_lo;                      // lat pass at the upper lon
         }
+        if (active) {
 #pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            if (f + u < f1) {
-                double r;
-                if (oob) r = __builtin_nan("");
-                else {
-                    double ya = (a_hi[u] - a_lo[u]) / lDx * ldx + a_lo[u];      // lat pass at the lower lon  :859
-                    double yb = (b_hi[u] - b_lo[u]) / lDx * ldx + b_lo[u];      // lat pass at the upper lon
-                    r = (yb - ya) / oDx * odx + ya;                            // lon pass                    :892
+            for (int u = 0; u < FU; ++u) {
+                if (f + u < f1) {
+                    double r = oob ? __builtin_nan("") : by_oDx.divide(yb[u] - ya[u]) * odx + ya[u];   // lon pass  :892
+                    po[(f + u) * plane_t] = (T)r;
                 }
-                po[(f + u) * plane_t] = (T)r;
             }
         }
     }
@@ -1652,6 +1726,13 @@ __global__ __launch_bounds__(BLOCK) void k_byteswap(long long n16, long long n, 
 __global__ void k_test_log(long long n, const double *__restrict__ in, double *__restrict__ out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = pgw_log(in[i]);
+}
+
+// SharedDivisor over arrays (diagnostic entry pgw_test_shared_div; tests compare it with IEEE division)
+__global__ void k_test_shared_div(long long n, const double *__restrict__ num, const double *__restrict__ den,
+                                  double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = SharedDivisor(den[i]).divide(num[i]);
 }
 
 // ln() of a small table with the device log (so table entries and per-column logs come from

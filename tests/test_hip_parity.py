@@ -339,6 +339,33 @@ def test_regrid_vs_oracle(F):
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14, equal_nan=True)
 
 
+@pytest.mark.parametrize('case', ['fine_multi_block', 'coarse_target', 'unsorted_lons', 'f32'])
+def test_regrid_block_window_paths(F, case):
+    """The regridding kernel stages the latitude pass of a block's source-column window in LDS; cover several
+    blocks per row with a ragged last one and the periodic wrap inside a block (fine target), windows wider than
+    the LDS tile (target coarser than the source -> direct gathers), target longitudes in arbitrary order, and
+    float32 storage - all against the oracle."""
+    from pgw4era5_amd import synthetic
+    if case == 'fine_multi_block':
+        g = synthetic.make_gcm_grid_case(nlat_src=24, nlon_src=48, nlat=19, nlon=700, nplev=2, ntime=3, seed=5)
+        g['targ_lon'] = g['targ_lon'] - 123.4                      # wrap somewhere inside a block
+    elif case == 'coarse_target':
+        g = synthetic.make_gcm_grid_case(nlat_src=40, nlon_src=1200, nlat=13, nlon=300, nplev=2, ntime=2, seed=6)
+    elif case == 'unsorted_lons':
+        g = synthetic.make_gcm_grid_case(nlat_src=24, nlon_src=60, nlat=11, nlon=333, nplev=3, ntime=1, seed=7)
+        g['targ_lon'] = np.random.default_rng(0).permutation(g['targ_lon'])
+    else:
+        g = synthetic.make_gcm_grid_case(nlat_src=30, nlon_src=64, nlat=21, nlon=515, nplev=3, ntime=2, seed=8, dtype=np.float32)
+    g['field'][0, 1, 3, 5] = np.nan
+    want = O.regrid_lat_lon(g['field'].astype(np.float64), g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon'])
+    got = F.regrid_field(g['field'], g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon'])
+    assert got.dtype == g['field'].dtype
+    tol = dict(rtol=1e-12, atol=1e-14) if case != 'f32' else dict(rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got, want, equal_nan=True, **tol)
+    assert np.isnan(got).sum() == np.isnan(want).sum()
+    assert np.isnan(want).sum() > 0 or case in ('coarse_target', 'unsorted_lons')     # a coarse target may miss the NaN cell
+
+
 def test_device_log_accuracy():
     """pgw_log (the logarithm every kernel uses) against numpy: <= 1 ulp on positive normal
     numbers, IEEE special cases through the ocml fallback."""
@@ -732,3 +759,29 @@ def test_harmonic_smoothing_golden_and_oracle(F, golden_harmonic):
         x[3, ..., 0] = np.nan                                   # NaN columns come back all NaN, the others untouched by them
         got = F.smooth_annual_cycle(x)
         np.testing.assert_allclose(got, O.filter_data_array(x), rtol=0, atol=1e-12 * 10, equal_nan=True)
+
+
+def test_shared_divisor_is_ieee_division():
+    """SharedDivisor (reciprocal once + three instructions per quotient) must give the correctly rounded IEEE
+    quotient - the same bits as numpy's `/` - over the operand ranges it is used with (grid spacings, ln-pressure
+    intervals, field differences) and far beyond; NaN numerators propagate."""
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(123)
+    n = 1 << 21
+    num = rng.normal(size=n) * 10.0 ** rng.uniform(-12, 12, n)
+    den = rng.uniform(0.5, 2.0, n) * 10.0 ** rng.uniform(-8, 8, n) * rng.choice([-1.0, 1.0], n)
+    num[:8] = [0.0, -0.0, np.nan, 1.0, 3.0, 1e-200, 1e200, 7.0]
+    den[:8] = [3.0, 3.0, 2.0, 3.0, 1.0, 1e-3, 1e3, 0.1]
+    # mantissa patterns that stress the rounding: numerators just around representable quotient boundaries
+    q = rng.uniform(1, 2, 4096)
+    d = rng.uniform(1, 2, 4096)
+    num[100:100 + 4096] = np.nextafter(q * d, np.inf)
+    den[100:100 + 4096] = d
+    dn, dd = ctx.to_device(num), ctx.to_device(den)
+    out = ctx.empty((n,), np.float64)
+    ctx._check(ctx.lib.pgw_test_shared_div(ctx.handle, n, dn.ptr, dd.ptr, out.ptr))
+    got = out.numpy()
+    with np.errstate(all='ignore'):
+        want = num / den
+    np.testing.assert_array_equal(got, want)          # equal doubles = equal bits, up to the sign of a zero quotient and NaN payloads
