@@ -1040,9 +1040,10 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
                         double da = a1, db = b1;
                         if (i1 != i2) {                                               // :575-578
                             double x1 = srcx(v, i1), x2 = srcx(v, i2);
-                            double dx = x - x1, Dx = x2 - x1;
-                            da = a1 + dx * (a2 - a1) / Dx;
-                            db = b1 + dx * (b2 - b1) / Dx;
+                            const double dx = x - x1;
+                            const SharedDivisor by_Dx(x2 - x1);                       // x1 < x < x2: finite, positive
+                            da = a1 + by_Dx.divide(dx * (a2 - a1));
+                            db = b1 + by_Dx.divide(dx * (b2 - b1));
                         }
                         if (THERMO) {
                             double rh_era = q_to_rh(cb[u][v], pa, ca[u][v]);           // step_03:91-94
@@ -1221,9 +1222,10 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         da = a_lo; db = b_lo;
                         if (i1 != i2) {                                            // :575-578
                             double x1 = sx1(i1), x2 = sx1(i2);
-                            double dx = x - x1, Dx = x2 - x1;
-                            da = a_lo + dx * (a_hi - a_lo) / Dx;
-                            db = b_lo + dx * (b_hi - b_lo) / Dx;
+                            const double dx = x - x1;
+                            const SharedDivisor by_Dx(x2 - x1);                    // x1 < x < x2: finite, positive
+                            da = a_lo + by_Dx.divide(dx * (a_hi - a_lo));
+                            db = b_lo + by_Dx.divide(dx * (b_hi - b_lo));
                         }
                     }
                     // ua, va on the plain plev axis
@@ -1241,9 +1243,10 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         dc = c_lo; dd = d_lo;
                         if (i1 != i2) {
                             double x1 = s_lnp[i1], x2 = s_lnp[i2];
-                            double dx = x - x1, Dx = x2 - x1;
-                            dc = c_lo + dx * (c_hi - c_lo) / Dx;
-                            dd = d_lo + dx * (d_hi - d_lo) / Dx;
+                            const double dx = x - x1;
+                            const SharedDivisor by_Dx(x2 - x1);
+                            dc = c_lo + by_Dx.divide(dx * (c_hi - c_lo));
+                            dd = d_lo + by_Dx.divide(dx * (d_hi - d_lo));
                         }
                     }
                     long long o = base + (long long)l * ncol;
@@ -1282,8 +1285,6 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
 
 // =====================================================================================
 // a10  bilinear regridding (lat then lon)                      functions.py:817-893
-// One thread per output element, lanes along target lon (coalesced writes; the source grid
-// of one field is ~0.6 MB and stays in L2).  slope*(x_new-x_lo)+y_lo as scipy interp1d.
 // =====================================================================================
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_zonal_mean_rows(long long nfield, int nlat_s, int nlon_s,
