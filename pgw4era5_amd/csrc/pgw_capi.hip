@@ -25,7 +25,7 @@ struct pgw_ctx {
     LoopMail *mail = nullptr;          // coherent host mailbox polled by the loop (PGW_DEVICE_LOOP=3/4)
     std::string err;
     long long err_col = -1;
-    DevStatus *d_status = nullptr;     // device
+    DevStatus *d_status = nullptr;     // device; [1] = alternate block of the loop passes (cleared by the pass before)
     DevStatus *h_status = nullptr;     // pinned host mirror
     // vertical grid
     int nlev = 0;
@@ -163,13 +163,13 @@ static int status_reset(pgw_ctx *ctx) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_status, ctx->h_status, sizeof(DevStatus), hipMemcpyHostToDevice, ctx->stream));
     return PGW_OK;
 }
-static int status_fetch(pgw_ctx *ctx) {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
+static int status_fetch(pgw_ctx *ctx, const DevStatus *from = nullptr) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_status, from ? from : ctx->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return PGW_OK;
 }
-static int status_check(pgw_ctx *ctx) {
-    int rc = status_fetch(ctx);
+static int status_check(pgw_ctx *ctx, const DevStatus *from = nullptr) {
+    int rc = status_fetch(ctx, from);
     if (rc) return rc;
     if (ctx->h_status->code != 0) {
         ctx->err_col = (long long)ctx->h_status->col;
@@ -233,7 +233,7 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
         hipEventCreateWithFlags(&c->loop_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[2], hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(&c->d_status, sizeof(DevStatus)) != hipSuccess ||
+        hipMalloc(&c->d_status, 2 * sizeof(DevStatus)) != hipSuccess ||
         hipHostMalloc(&c->h_status, sizeof(DevStatus)) != hipSuccess ||
         hipMalloc(&c->d_small, SMALL_BYTES) != hipSuccess ||
         hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
@@ -726,7 +726,8 @@ static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                        const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
                        double *delta_ps, double *adj_ps, double p_ref, const double *p_ref_field,
                        double adj_factor, int full_column, int apply_adj = 1, LoopState *ls = nullptr,
-                       double thresh = 0.0) {
+                       double thresh = 0.0, DevStatus *st = nullptr, DevStatus *clear = nullptr) {
+    if (!st) st = ctx->d_status;
     int vec = pick_vec(dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field}, 2);
     // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
     Levels lv = levels_of(ctx);
@@ -735,12 +736,12 @@ static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, 2>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
                                                     dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
                                                     (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, ctx->d_status, ls, thresh));
+                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, ls, thresh, clear));
     else
         DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
                                                     dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
                                                     (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, ctx->d_status, ls, thresh));
+                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, ls, thresh, clear));
     return PGW_OK;
 }
 
@@ -909,14 +910,18 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         if (!status_armed && (rc = status_reset(ctx))) return rc;
         launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column);
         HIPCHK(ctx, hipGetLastError());
-        if (!device_loop_env() && (rc = status_check(ctx))) return rc;
+        // status_armed (pgw_step03_file with the model-top check off): nothing is read back before the first pass;
+        // the status block keeps the first error any kernel reported, in stream order, so the first pass's check
+        // raises what an immediate check would have raised
+        if (!device_loop_env() && !status_armed && (rc = status_check(ctx))) return rc;
         // g * (time-interpolated zg delta at p_ref)   step_03:292-295
         DISPATCH_T(dtype, {
             DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
-            hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi);
+            hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi,
+                               delta_ps, adj_ps);                                       // + delta_ps = adj_ps = 0  :182-184
         });
     }
-    HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
+    if (local) HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
 
     if (!local && device_loop_env() >= 2) {
         // Modes 2-4 (see device_loop_env): every pass first checks the device-side `done` flag (set by the last
@@ -1037,8 +1042,14 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     double phi_ref_max_error = INFINITY;                                   // :186
     int it = 1;                                                            // :188
     unsigned long long touched = 0;
+    // Fixed p_ref: the passes alternate between the two status blocks and each pass clears the other one for its
+    // successor, so no reset copy is enqueued per pass (the read-back of the block being cleared was enqueued
+    // before this pass was launched).
+    DevStatus *blk[2] = {ctx->d_status, ctx->d_status + 1};
     while (phi_ref_max_error > thresh) {                                   // :189
-        if ((rc = status_reset(ctx))) return rc;
+        const bool reset_here = local || it == 1;
+        if (reset_here && !(status_armed && it == 1) && (rc = status_reset(ctx))) return rc;
+        DevStatus *cur = local ? ctx->d_status : blk[(it - 1) & 1];
         if (local) {
             // delta_ps += adj_ps ; per-column p_ref (never lower than last pass) ; g*zg at that level
             DISPATCH_T(dtype, {
@@ -1052,10 +1063,10 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                         adj_factor, full_column, 0);
         } else {
             launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
-                        adj_factor, full_column);
+                        adj_factor, full_column, 1, nullptr, 0.0, cur, blk[it & 1]);
         }
         HIPCHK(ctx, hipGetLastError());
-        if ((rc = status_check(ctx))) return rc;
+        if ((rc = status_check(ctx, cur))) return rc;
         phi_ref_max_error = max_err_of(ctx);                               // :308
         touched += ctx->h_status->levels_touched;
         if (max_err_hist && it - 1 < hist_len) max_err_hist[it - 1] = phi_ref_max_error;
@@ -1172,7 +1183,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         const unsigned int grid = nblocks((long long)ntime * ncol, tpb);
         // one host synchronisation per file: without the model-top check nothing has to be read back
         // between the kernels (errors stay in the status block until the loop's final check)
-        const bool defer = !check_top && device_loop_env() && !a->local_p_ref;
+        const bool defer = !check_top && !a->local_p_ref;    // kernel-reported errors are read with the first loop pass
 #define LAUNCH_PAIR(THERMO, TPB, FA, FB, D3, DS, PH, OA, OB, OH, STREAM)                                                      \
     do {                                                                                                               \
         if (lds > 64 * 1024)                                                                                           \
@@ -1279,7 +1290,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                      a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a, a->x_hi,
                      a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
                      a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev, akbk_N,
-                     !check_top && device_loop_env() && !a->local_p_ref, qv_done);
+                     !check_top && !a->local_p_ref, qv_done);
     a->levels_touched = ctx->last_levels_touched;
     if (!check_top && side_stream_env()) {
         // join: later work on the main stream (and the caller after the next synchronisation) sees U_out, V_out

@@ -68,9 +68,11 @@ __device__ __forceinline__ void storev(T *__restrict__ p, const double (&in)[V])
     *reinterpret_cast<Pack<T, V> *>(p) = t;
 }
 
+// first reported code wins (kernels of a stream run in order, so an earlier kernel's error outlives later ones);
+// the column is the smallest one that reported THAT code
 __device__ __forceinline__ void report(DevStatus *st, int code, long long col) {
-    atomicMin(&st->col, (unsigned long long)col);
-    atomicCAS(&st->code, 0, code);
+    int prev = atomicCAS(&st->code, 0, code);
+    if (prev == 0 || prev == code) atomicMin(&st->col, (unsigned long long)col);
 }
 
 // ---- division by a value that many numerators share ---------------------------------------
@@ -90,6 +92,9 @@ struct SharedDivisor {
         y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
         r = y;
     }
+    // divisor known at compile time: r must be the double nearest to 1/den (then the quotient below is the
+    // correctly rounded one - Markstein's theorem - and therefore the same bits as any IEEE division)
+    __device__ __forceinline__ constexpr SharedDivisor(double den, double rcp_nearest) : d(den), r(rcp_nearest) {}
     __device__ __forceinline__ double divide(double n) const {
         double q = n * r;
         return __builtin_fma(__builtin_fma(-d, q, n), r, q);
@@ -185,8 +190,9 @@ __device__ __forceinline__ double e_to_q(double vapp, double pa) {         // :6
 __device__ __forceinline__ double q_to_rh(double hus, double pa, double ta) {   // :107-116
     return (q_to_e(hus, pa) / esat_mixed(ta)) * 100;
 }
+__device__ __forceinline__ double div_by_100(double x) { return SharedDivisor(100.0, 0.01).divide(x); }
 __device__ __forceinline__ double rh_to_e(double hur, double ta) {         // :123
-    return hur / 100 * esat_mixed(ta);
+    return div_by_100(hur) * esat_mixed(ta);
 }
 __device__ __forceinline__ double rh_to_q(double hur, double pa, double ta) {   // :118-125
     return e_to_q(rh_to_e(hur, ta), pa);

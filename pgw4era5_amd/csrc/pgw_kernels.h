@@ -340,13 +340,20 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
                                                           double *__restrict__ delta_ps, double *__restrict__ adj_ps,
                                                           double p_ref_s, const double *__restrict__ p_ref_f,
                                                           double adj_factor, int full_column, int apply_adj,
-                                                          DevStatus *st, LoopState *ls, double thresh) {
+                                                          DevStatus *st, LoopState *ls, double thresh,
+                                                          DevStatus *clear) {
     __shared__ double s_max[BLOCK / 64];
     __shared__ unsigned int s_valid[BLOCK / 64];
     __shared__ double s_lev[LEVTAB_DOUBLES];
     // device-controlled loop: a pass enqueued after convergence is a no-op (the flag was written by
     // an earlier kernel on this stream, so the kernel boundary makes it visible)
     if (ls && ls->done) return;
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) {       // status block of the NEXT pass (host-controlled loop)
+        DevStatus z;
+        z.code = 0; z.nan_seen = 0; z.col = ~0ull; z.max_bits = 0; z.valid = 0;
+        z.min_targ_bits = ~0ull; z.min_src_bits = ~0ull; z.levels_touched = 0;
+        *clear = z;
+    }
     LevTab lt = stage_levels<true, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
@@ -1599,9 +1606,13 @@ __global__ __launch_bounds__(BLOCK) void k_update_ps(long long n, const T *__res
 
 // g * time-interpolated zg delta at p_ref -> fp64 loop constant (step_03:292-295)
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z, double g, double *__restrict__ out) {
+__global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z, double g, double *__restrict__ out,
+                                                     double *__restrict__ zero_a, double *__restrict__ zero_b) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) out[i] = z.get(i) * g;
+    if (i < n) {
+        out[i] = z.get(i) * g;
+        if (zero_a) { zero_a[i] = 0.0; zero_b[i] = 0.0; }          // delta_ps, adj_ps of the loop start (step_03:182-184)
+    }
 }
 
 // surface riders with the time lerp of the three 2-D deltas fused in (step_03:103-146)
@@ -1733,7 +1744,7 @@ __global__ void k_test_log(long long n, const double *__restrict__ in, double *_
 __global__ void k_test_shared_div(long long n, const double *__restrict__ num, const double *__restrict__ den,
                                   double *__restrict__ out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = SharedDivisor(den[i]).divide(num[i]);
+    if (i < n) out[i] = (den[i] == 100.0) ? div_by_100(num[i]) : SharedDivisor(den[i]).divide(num[i]);
 }
 
 // ln() of a small table with the device log (so table entries and per-column logs come from

@@ -778,6 +778,8 @@ def test_shared_divisor_is_ieee_division():
     d = rng.uniform(1, 2, 4096)
     num[100:100 + 4096] = np.nextafter(q * d, np.inf)
     den[100:100 + 4096] = d
+    den[10000:400000] = 100.0                                   # the compile-time divisor of rh_to_e (hur / 100)
+    num[10000:200000] = rng.uniform(-50, 200, 190000)
     dn, dd = ctx.to_device(num), ctx.to_device(den)
     out = ctx.empty((n,), np.float64)
     ctx._check(ctx.lib.pgw_test_shared_div(ctx.handle, n, dn.ptr, dd.ptr, out.ptr))
