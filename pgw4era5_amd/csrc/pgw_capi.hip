@@ -229,7 +229,6 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
         hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&c->h_loop, 3 * sizeof(LoopState)) != hipSuccess ||
-        hipHostMalloc(&c->mail, sizeof(LoopMail), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->loop_ev[2], hipEventDisableTiming) != hipSuccess ||
@@ -937,6 +936,8 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         LoopState init;
         memset(&init, 0, sizeof(init));
         if (mailbox) {
+            if (!ctx->mail)                                                 // opt-in modes only: allocated on first use
+                HIPCHK(ctx, hipHostMalloc(&ctx->mail, sizeof(LoopMail), hipHostMallocMapped | hipHostMallocCoherent));
             void *dmail = nullptr;
             HIPCHK(ctx, hipHostGetDevicePointer(&dmail, ctx->mail, 0));
             init.mail = (unsigned long long)(uintptr_t)dmail;
