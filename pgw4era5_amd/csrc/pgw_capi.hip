@@ -508,11 +508,7 @@ static int launch_integ_geopot(pgw_ctx *ctx, int dtype, int nlev, int ntime, lon
                                                 dim3(BLOCK), 0, ctx->stream, nlev, ntime, ncol, (const T *)pa_hl,     \
                                                 (const T *)zgs, (const T *)ta, (const T *)hus, p_ref,                  \
                                                 (const T *)p_ref_field, (TO_ *)phi_ref, full_column, ctx->d_status))
-    const char *gu = getenv("PGW_GEO_U");          // tuning knob: levels per chunk of the signature-faithful kernel
-    int u = gu ? atoi(gu) : 4;
-    if (out_f64) { LAUNCH_GEO(4, double); }
-    else if (u == 2) { LAUNCH_GEO(2, T); }
-    else if (u == 8) { LAUNCH_GEO(8, T); }
+    if (out_f64) { LAUNCH_GEO(4, double); }      // levels per chunk: 2 / 4 / 8 measured the same
     else { LAUNCH_GEO(4, T); }
 #undef LAUNCH_GEO
     return PGW_OK;
@@ -716,10 +712,6 @@ extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int npl
 #ifndef STEP_U
 #define STEP_U 2      // measured 3 % faster than 4 for the pass kernel (finer stop above p_ref, fewer VGPRs)
 #endif
-static int step_u() {
-    const char *e = getenv("PGW_STEP_U");      // tuning knob: levels per pipelined chunk of the pass kernel
-    return (e && e[0] == '2') ? 2 : STEP_U;
-}
 
 static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *evap,
                        const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
@@ -731,16 +723,10 @@ static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_ADJUST_PS_STEP);
-    if (step_u() == 2)
-        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, 2>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                    dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
-                                                    (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, ls, thresh, clear));
-    else
-        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                    dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
-                                                    (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                    p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, ls, thresh, clear));
+    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
+                                                (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
+                                                p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, ls, thresh, clear));
     return PGW_OK;
 }
 
@@ -1412,19 +1398,11 @@ extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, in
                                    nlat_s, nlon_s, (const T *)src, south_row, north_row, dpole);
             // z-slices: enough blocks to fill 256 CUs several times over even for small target grids
             long long xy = (long long)nblocks(nlon_t, BLOCK) * nlat_t;
-            const char *gzw = getenv("PGW_REGRID_BLOCKS");   // tuning knob: target number of blocks
-            long long want = ((gzw ? atoll(gzw) : 8192) + xy - 1) / xy;
+            long long want = (8192 + xy - 1) / xy;
             unsigned int gz = (unsigned int)(want < 1 ? 1 : (want > nfield ? nfield : want));
-            const char *fu = getenv("PGW_REGRID_FU");     // tuning knob: planes per step
-            if (fu && fu[0] == '8')
-                hipLaunchKernelGGL((k_regrid<T, 8>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
-            else if (fu && fu[0] == '2')
-                hipLaunchKernelGGL((k_regrid<T, 2>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
-            else
-                hipLaunchKernelGGL((k_regrid<T, 4>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+            // 4 planes per step (2: 6 % slower, 8: the same); ~8 k blocks (40 k: 14 % slower, one z-slice: 3 % slower)
+            hipLaunchKernelGGL((k_regrid<T, 4>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                               nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
         });
     }
     HIPCHK(ctx, hipGetLastError());

@@ -649,7 +649,7 @@ def test_whole_file_errors_reach_python():
 
 @pytest.mark.parametrize('env', [dict(PGW_QUAD='0'), dict(PGW_QUAD='0', PGW_SIDE_STREAM='1'),
                                  dict(PGW_QUAD='0', PGW_PAIR_STAGED='1'), dict(PGW_QUAD='0', PGW_PAIR_VEC='1'),
-                                 dict(PGW_FULL_COLUMN='1'), dict(PGW_STEP_U='2'), dict(PGW_FORCE_VEC1='1')])
+                                 dict(PGW_FULL_COLUMN='1'), dict(PGW_FORCE_VEC1='1')])
 def test_kernel_variants_are_bit_identical(monkeypatch, env):
     """Every selectable variant of the file path (pair kernels instead of the quad kernel, side stream,
     LDS-staged source columns, 16 B per lane, full-column passes, chunk size, scalar columns) produces
