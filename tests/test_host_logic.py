@@ -96,6 +96,32 @@ def test_native_reader_matches_scipy_reader(tmp_path, monkeypatch):
         ncio.open_dataset(str(tmp_path / 'trunc.nc'))
 
 
+def test_writer_variants_produce_the_same_data(tmp_path, monkeypatch):
+    """Native writer with 1 / 8 pwrite threads and the scipy writer of the first version (PGW_NC_WRITER=scipy):
+    files read back to identical datasets; the native variants are byte-identical."""
+    from pgw4era5_amd import ncio
+    rng = np.random.default_rng(4)
+    monkeypatch.setattr(ncio, 'BIG_VARIABLE', 4096)                      # several 64 MiB-style pieces are not needed: any split works
+    ds = ncio.Dataset(attrs=dict(title='w'))
+    ds['lat'] = ncio.Field(np.linspace(-5, 5, 11), ('lat',)); ds['lon'] = ncio.Field(np.arange(13.0), ('lon',))
+    ds['lev'] = ncio.Field(np.arange(7, dtype=np.int32), ('lev',))
+    ds['a'] = ncio.Field(rng.normal(size=(7, 11, 13)).astype(np.float32), ('lev', 'lat', 'lon'), attrs=dict(units='K'))
+    ds['b'] = ncio.Field(rng.normal(size=(7, 11, 13)), ('lev', 'lat', 'lon'))
+    ds['c'] = ncio.Field(rng.integers(0, 9, size=(11, 13)).astype(np.int16), ('lat', 'lon'))
+    ncio.to_netcdf(ds, str(tmp_path / 't8.nc'))
+    monkeypatch.setenv('PGW_NC_WRITE_THREADS', '1')
+    ncio.to_netcdf(ds, str(tmp_path / 't1.nc'))
+    monkeypatch.setenv('PGW_NC_WRITER', 'scipy')
+    ncio.to_netcdf(ds, str(tmp_path / 'sp.nc'))
+    assert open(tmp_path / 't8.nc', 'rb').read() == open(tmp_path / 't1.nc', 'rb').read()
+    a, b = ncio.open_dataset(str(tmp_path / 't8.nc')), ncio.open_dataset(str(tmp_path / 'sp.nc'))
+    assert set(a.variables) == set(b.variables)
+    for k in a.variables:
+        assert a[k].dims == b[k].dims and a[k].values.dtype == b[k].values.dtype
+        np.testing.assert_array_equal(a[k].values, b[k].values, err_msg=k)
+    assert a['a'].attrs['units'] == b['a'].attrs['units'] == 'K'
+
+
 def test_decode_cf_time_calendars():
     from pgw4era5_amd.ncio import decode_cf_time
     got = decode_cf_time([0, 31, 59.5], 'days since 1850-01-01 00:00:00', 'proleptic_gregorian')
