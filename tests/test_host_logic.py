@@ -96,6 +96,46 @@ def test_native_reader_matches_scipy_reader(tmp_path, monkeypatch):
         ncio.open_dataset(str(tmp_path / 'trunc.nc'))
 
 
+def test_native_reader_cdf5(tmp_path):
+    """CDF-5 (64-bit data) header layout: counts, dimension ids and sizes are 64-bit, extra integer types.  No
+    writer for this format exists in the build environment, so the file is assembled by hand from the format
+    description (name = count + padded bytes; dimension list 0x0A; attribute list 0x0C; variable list 0x0B)."""
+    import struct
+    from pgw4era5_amd import ncio
+
+    def name(b):
+        return struct.pack('>q', len(b)) + b + b'\x00' * (-len(b) % 4)
+
+    x = (np.arange(5) * 1.5).astype('>f8')                                     # arithmetic returns native order: convert last
+    big = (np.arange(12, dtype=np.uint64) + 2 ** 40).reshape(3, 4).astype('>u8')
+    recs = np.arange(2 * 4, dtype='>i2').reshape(2, 4)                         # record variable, 8 bytes per record
+    dims = [(b't', 0), (b'x', 5), (b'y', 4), (b'z', 3)]
+    variables = [(b'x', [1], 6, x.nbytes), (b'big', [3, 2], 11, big.nbytes), (b'r', [0, 2], 3, 8)]   # name, dim ids, nc_type, vsize
+
+    def header(begins):
+        h = b'CDF\x05' + struct.pack('>q', 2)                                  # numrecs = 2
+        h += struct.pack('>iq', 0x0A, len(dims)) + b''.join(name(n) + struct.pack('>q', ln) for n, ln in dims)
+        h += struct.pack('>iq', 0x0C, 1) + name(b'note') + struct.pack('>iq', 2, 3) + b'abc\x00'
+        h += struct.pack('>iq', 0x0B, len(variables))
+        for (nm, ids, typ, vs), bg in zip(variables, begins):
+            h += name(nm) + struct.pack('>q', len(ids)) + b''.join(struct.pack('>q', d) for d in ids)
+            h += struct.pack('>iq', 0, 0)                                      # no attributes
+            h += struct.pack('>iqq', typ, vs, bg)
+        return h
+
+    n0 = len(header([0, 0, 0]))
+    begins = [n0, n0 + x.nbytes, n0 + x.nbytes + big.nbytes]
+    p = tmp_path / 'c5.nc'
+    p.write_bytes(header(begins) + x.tobytes() + big.tobytes() + recs.tobytes())
+    ds = ncio.open_dataset(str(p), decode_times=False)
+    assert ds.attrs['note'] == 'abc'
+    np.testing.assert_array_equal(ds['x'].values, x.astype('f8'))
+    assert ds['big'].values.dtype == np.uint64 and ds['big'].dims == ('z', 'y')
+    np.testing.assert_array_equal(ds['big'].values, big.astype('u8'))
+    assert ds['r'].dims == ('t', 'y') and ds['r'].shape == (2, 4)
+    np.testing.assert_array_equal(ds['r'].values, recs.astype('i2'))
+
+
 def test_writer_variants_produce_the_same_data(tmp_path, monkeypatch):
     """Native writer with 1 / 8 pwrite threads and the scipy writer of the first version (PGW_NC_WRITER=scipy):
     files read back to identical datasets; the native variants are byte-identical."""
