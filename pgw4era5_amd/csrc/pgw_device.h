@@ -68,6 +68,23 @@ __device__ __forceinline__ void storev(T *__restrict__ p, const double (&in)[V])
     *reinterpret_cast<Pack<T, V> *>(p) = t;
 }
 
+// ---- addressing with 32-bit byte offsets ---------------------------------------------------
+// `base + (long long)index` makes the compiler carry a 64-bit address per array and lane (two VGPRs and a 64-bit
+// add per access).  When a whole array is smaller than 4 GiB the element can be addressed as uniform base (SGPR
+// pair) + 32-bit byte offset in one VGPR, which is the form global_load / global_store take natively (saddr +
+// voffset): one offset register serves every array of the same shape.  O is the offset type: unsigned int for
+// that form, unsigned long long for arrays of 4 GiB and more.
+using boff32 = unsigned int;          // byte offset types for ld_off / st_off
+using boff64 = unsigned long long;
+template <typename T, typename O>
+__device__ __forceinline__ T ld_off(const T *__restrict__ base, O byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <typename T, typename O>
+__device__ __forceinline__ void st_off(T *__restrict__ base, O byte_off, T v) {
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
 // first reported code wins (kernels of a stream run in order, so an earlier kernel's error outlives later ones);
 // the column is the smallest one that reported THAT code
 __device__ __forceinline__ void report(DevStatus *st, int code, long long col) {

@@ -741,6 +741,15 @@ struct DeltaSrc {
         double va = (double)a[off];
         return (va - vb) / x_hi * x_new + vb;                     // :288-292 (scipy interp1d linear)
     }
+    // same, addressed by byte offset (ld_off); the division by the kernel-wide x_hi goes through a reciprocal the
+    // caller computed once (SharedDivisor: same quotient bits)
+    template <typename O>
+    __device__ __forceinline__ double get_at(O byte_off, const SharedDivisor &by_x_hi) const {
+        double vb = (double)ld_off(b, byte_off);
+        if (!a) return vb;
+        double va = (double)ld_off(a, byte_off);
+        return by_x_hi.divide(va - vb) * x_new + vb;
+    }
 };
 
 template <typename T, bool HAS_SFC>
@@ -1103,7 +1112,7 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
 #ifndef QUAD_MINW
 #define QUAD_MINW 3
 #endif
-template <typename T, int U, int TPB>
+template <typename T, int U, int TPB, typename O>
 __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                        const T *__restrict__ fT, const T *__restrict__ fQ,
                                                        const T *__restrict__ fU, const T *__restrict__ fV,
@@ -1127,11 +1136,19 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
     long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
     double min_t = __builtin_inf(), min_s = __builtin_inf();
     int nanflag = 0;
+    // every delta record of a file is interpolated to the same instant: ONE (x_hi, x_new) pair and one reciprocal
+    // instead of the seven copies in the argument structs (28 SGPRs; the kernel was spilling scalars to VGPR lanes)
+    const double x_hi = dth.a.x_hi, x_new = dth.a.x_new;
+    const SharedDivisor by_x_hi(x_hi);                      // unused (a == nullptr) when the instant is a record
+    const DeltaSrc<T> sTa{dth.a.b, dth.a.a, x_hi, x_new}, sHur{dth.b.b, dth.b.a, x_hi, x_new};
+    const DeltaSrc<T> sUa{dw.a.b, dw.a.a, x_hi, x_new}, sVa{dw.b.b, dw.b.a, x_hi, x_new};
     if (flat < (long long)ntime * ncol) {
         const int N = lv.nlev;
         long long t = flat / ncol, c = flat - t * ncol;
-        long long dbase = t * S * ncol + c;
-        long long base = t * N * ncol + c;
+        // byte offsets (type O, see ld_off): delta records (ntime, S, ncol), fields (ntime, N, ncol)
+        const O row = (O)((unsigned long long)ncol * sizeof(T));
+        const O dbase = (O)((unsigned long long)(t * S * ncol + c) * sizeof(T));
+        const O base = (O)((unsigned long long)(t * N * ncol + c) * sizeof(T));
         const double ps = (double)PS[flat];
         // ---- surface insertion for ta / hur (replace_delta_sfc, functions.py:343-366)
         int ksfc = -1;
@@ -1163,24 +1180,24 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
         double c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;       // ua, va
         auto fetch1 = [&](int i1) {
             if (ci1 == i1) return;
-            long long o = dbase + (long long)(S - 1 - i1) * ncol;
+            O o = dbase + (O)(S - 1 - i1) * row;
             if (ci1 + 1 == i1) { a_lo = a_hi; b_lo = b_hi; }
-            else { a_lo = is_sfc(i1) ? sfa : dth.a.get(o); b_lo = is_sfc(i1) ? sfb : dth.b.get(o); }
+            else { a_lo = is_sfc(i1) ? sfa : sTa.get_at(o, by_x_hi); b_lo = is_sfc(i1) ? sfb : sHur.get_at(o, by_x_hi); }
             int ih = (i1 + 1 < S) ? i1 + 1 : i1;
-            long long oh = dbase + (long long)(S - 1 - ih) * ncol;
-            a_hi = is_sfc(ih) ? sfa : dth.a.get(oh);
-            b_hi = is_sfc(ih) ? sfb : dth.b.get(oh);
+            O oh = dbase + (O)(S - 1 - ih) * row;
+            a_hi = is_sfc(ih) ? sfa : sTa.get_at(oh, by_x_hi);
+            b_hi = is_sfc(ih) ? sfb : sHur.get_at(oh, by_x_hi);
             ci1 = i1;
         };
         auto fetch2 = [&](int i1) {
             if (ci2 == i1) return;
-            long long o = dbase + (long long)(S - 1 - i1) * ncol;
+            O o = dbase + (O)(S - 1 - i1) * row;
             if (ci2 + 1 == i1) { c_lo = c_hi; d_lo = d_hi; }
-            else { c_lo = dw.a.get(o); d_lo = dw.b.get(o); }
+            else { c_lo = sUa.get_at(o, by_x_hi); d_lo = sVa.get_at(o, by_x_hi); }
             int ih = (i1 + 1 < S) ? i1 + 1 : i1;
-            long long oh = dbase + (long long)(S - 1 - ih) * ncol;
-            c_hi = dw.a.get(oh);
-            d_hi = dw.b.get(oh);
+            O oh = dbase + (O)(S - 1 - ih) * row;
+            c_hi = sUa.get_at(oh, by_x_hi);
+            d_hi = sVa.get_at(oh, by_x_hi);
             ci2 = i1;
         };
         int j1 = 0, j2 = 0;
@@ -1189,8 +1206,8 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
         double nT[U], nQ[U], nU[U], nV[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            long long o = base + (long long)(u < N ? u : N - 1) * ncol;
-            nT[u] = (double)fT[o]; nQ[u] = (double)fQ[o]; nU[u] = (double)fU[o]; nV[u] = (double)fV[o];
+            O o = base + (O)(u < N ? u : N - 1) * row;
+            nT[u] = (double)ld_off(fT, o); nQ[u] = (double)ld_off(fQ, o); nU[u] = (double)ld_off(fU, o); nV[u] = (double)ld_off(fV, o);
         }
         for (int l0 = 0; l0 < N; l0 += U) {
             double cT[U], cQ[U], cU[U], cV[U];
@@ -1199,8 +1216,8 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
             if (l0 + U < N) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    long long o = base + (long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol;
-                    nT[u] = (double)fT[o]; nQ[u] = (double)fQ[o]; nU[u] = (double)fU[o]; nV[u] = (double)fV[o];
+                    O o = base + (O)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * row;
+                    nT[u] = (double)ld_off(fT, o); nQ[u] = (double)ld_off(fQ, o); nU[u] = (double)ld_off(fU, o); nV[u] = (double)ld_off(fV, o);
                 }
             }
 #pragma unroll
@@ -1256,17 +1273,17 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                             dd = d_lo + by_Dx.divide(dx * (d_hi - d_lo));
                         }
                     }
-                    long long o = base + (long long)l * ncol;
-                    oU[o] = (T)(cU[u] + dc);                                       // step_03:170-173
-                    oV[o] = (T)(cV[u] + dd);
+                    const O o = base + (O)l * row;
+                    st_off(oU, o, (T)(cU[u] + dc));                                // step_03:170-173
+                    st_off(oV, o, (T)(cV[u] + dd));
                     double rh_era = q_to_rh(cQ[u], pa, cT[u]);                     // step_03:91-94
                     double ta_pgw = cT[u] + da;
                     double hur_pgw = rh_era + db;
-                    oT[o] = (T)ta_pgw;
+                    st_off(oT, o, (T)ta_pgw);
                     double e_pgw = rh_to_e(hur_pgw, ta_pgw);                       // functions.py:123
-                    if (l < n_pure) oQ[o] = (T)e_to_q(e_pgw, pa);                  // pa == akm[l] for every finite ps
-                    else oE[o] = (T)e_pgw;
-                    if (oHur) oHur[o] = (T)hur_pgw;
+                    if (l < n_pure) st_off(oQ, o, (T)e_to_q(e_pgw, pa));           // pa == akm[l] for every finite ps
+                    else st_off(oE, o, (T)e_pgw);
+                    if (oHur) st_off(oHur, o, (T)hur_pgw);
                 }
             }
         }
