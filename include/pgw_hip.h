@@ -319,6 +319,11 @@ int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, voi
  * pgw_log: fdlibm log kernel for positive normal finite x, ocml log otherwise); device fp64 arrays */
 int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out);
 
+/* diagnostic: out[i] = pgw_exp(in[i]) (pgw_device.h: the device library's exp arithmetic written with explicit FMAs, the
+ * exponential of every e_sat evaluation), ref[i] = exp(in[i]) of the device library; device fp64 arrays.  Tests require
+ * out == ref bit for bit and <= 1 ulp from numpy. */
+int pgw_test_exp(pgw_ctx *ctx, long long n, const double *in, double *out, double *ref);
+
 /* diagnostic: out[i] = num[i] / den[i] through the shared-divisor path (pgw_device.h SharedDivisor: reciprocal once,
  * three instructions per quotient) that the regridding and delta kernels use where many numerators share a divisor;
  * device fp64 arrays.  Tests require the IEEE quotient bit for bit. */

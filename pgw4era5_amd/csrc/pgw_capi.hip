@@ -1299,6 +1299,13 @@ if (o32)
 
 extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx->last_levels_touched; }
 
+extern "C" int pgw_test_exp(pgw_ctx *ctx, long long n, const double *in, double *out, double *ref) {
+    NEED(ctx, n >= 1 && in && out && ref, "bad argument");
+    hipLaunchKernelGGL(k_test_exp, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out, ref);
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 extern "C" int pgw_test_shared_div(pgw_ctx *ctx, long long n, const double *num, const double *den, double *out) {
     NEED(ctx, n >= 1 && num && den && out, "bad argument");
     hipLaunchKernelGGL(k_test_shared_div, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, num, den, out);

@@ -135,7 +135,19 @@ __device__ __forceinline__ double no_speculate(double x) {
     return x;
 }
 
-__device__ __forceinline__ double pgw_log(double x) {
+// one Horner step a*b + c as the three-address v_fma_f64, c (a coefficient that stays live) in its own register
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#ifdef PGW_NO_FMA3
+    return __builtin_fma(a, b, c);
+#else
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
+// F3: Horner steps as three-address FMAs (fma3) - for kernels whose register budget is not the binding one
+template <bool F3>
+__device__ __forceinline__ double pgw_log_impl(double x) {
     if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0))
         return log(no_speculate(x));
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -155,19 +167,54 @@ __device__ __forceinline__ double pgw_log(double x) {
     double dk = (double)k;
     double z = s * s;
     double w = z * z;
-    double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
-    double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    double t1, t2;
+    if (F3) {
+        t1 = w * fma3(w, fma3(w, Lg6, Lg4), Lg2);
+        t2 = z * fma3(w, fma3(w, fma3(w, Lg7, Lg5), Lg3), Lg1);
+    } else {
+        t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+        t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    }
     double R = t2 + t1;
     double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)) - f);
 }
+__device__ __forceinline__ double pgw_log(double x) { return pgw_log_impl<false>(x); }
+__device__ __forceinline__ double pgw_log_f3(double x) { return pgw_log_impl<true>(x); }    // same bits
+
+// ---- exponential --------------------------------------------------------------------------
+// The same arithmetic as the device library's exp(double) - n = rint(x log2 e), r = x - n ln2 (two FMAs),
+// degree-11 polynomial in r (Horner), ldexp, the library's two range selects - written out with explicit FMAs.
+// Same operations and constants, hence the same bits as exp() (tests/...::test_device_exp_is_library_exp); the point
+// is code generation: for most of the inlined library instances in the delta kernels the compiler forms each Horner
+// step as v_mov_b64 (copy of the coefficient) + v_fmac, two instructions, where one three-address v_fma_f64 does.
+__device__ __forceinline__ double pgw_exp(double x) {
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = __builtin_fma(-0x1.62e42fefa39efp-1, n, x);
+    r = __builtin_fma(-0x1.abc9e3b39803fp-56, n, r);
+    double p = __builtin_fma(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
+    p = fma3(r, p, 0x1.71dee623fde64p-19);
+    p = fma3(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma3(r, p, 0x1.a01a014761f6ep-13);
+    p = fma3(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma3(r, p, 0x1.1111111122322p-7);
+    p = fma3(r, p, 0x1.55555555502a1p-5);
+    p = fma3(r, p, 0x1.5555555555511p-3);
+    p = fma3(r, p, 0x1.000000000000bp-1);
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    double v = __builtin_ldexp(p, (int)n);
+    v = (1024.0 < x) ? __builtin_inf() : v;          // NaN compares false: the NaN from the arithmetic is kept
+    v = (x < -1075.0) ? 0.0 : v;
+    return v;
+}
 
 // ---- humidity thermodynamics (functions.py:58-125), operation order as written there ----
 __device__ __forceinline__ double esat_water(double ta) {   // :74-89 water
-    return 611.21 * exp(17.502 * (ta - 273.16) / (ta - 32.19));
+    return 611.21 * pgw_exp(17.502 * (ta - 273.16) / (ta - 32.19));
 }
 __device__ __forceinline__ double esat_ice(double ta) {     // :74-89 ice (a4 = -0.7)
-    return 611.21 * exp(22.587 * (ta - 273.16) / (ta - (-0.7)));
+    return 611.21 * pgw_exp(22.587 * (ta - 273.16) / (ta - (-0.7)));
 }
 // :91-105.  alpha = 1 (T>=T0), 0 (T<=Ti), ((T-Ti)/(T0-Ti))^2 in between, NaN for NaN T.
 // alpha*e_w + (1-alpha)*e_i is evaluated in full only in the mixed range; for alpha in {0,1}
@@ -181,7 +228,7 @@ __device__ __forceinline__ double esat_mixed(double ta) {
     const bool warm = (ta >= T0);
     const double a3 = warm ? 17.502 : 22.587;
     const double a4 = warm ? 32.19 : -0.7;
-    double e1 = 611.21 * exp(a3 * (ta - T0) / (ta - a4));        // e_w if warm else e_i (NaN for NaN ta)
+    double e1 = 611.21 * pgw_exp(a3 * (ta - T0) / (ta - a4));    // e_w if warm else e_i (NaN for NaN ta)
     if (warm) return e1;
     if (ta <= Ti) {
         if (__builtin_expect(!(ta > 40.0), 0)) {                 // unphysical cold: literal expression, 0*e_w may be NaN/inf

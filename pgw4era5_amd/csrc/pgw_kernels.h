@@ -994,7 +994,8 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
             a1 = ca_lo[v]; b1 = cb_lo[v];
             if (i2 != i1) { a2 = ca_hi[v]; b2 = cb_hi[v]; } else { a2 = a1; b2 = b1; }
         };
-        auto srcx = [&](int v, int i) -> double { return (THERMO && i == sc[v].ksfc) ? sc[v].lnps : s_lnp[i]; };
+        auto srcx = [&](int v, int i) -> double {          // unconditional LDS read + select, as in k_delta_quad
+            double x = s_lnp[i]; asm("" : "+v"(x)); return (THERMO && i == sc[v].ksfc) ? sc[v].lnps : x; };
         // software pipeline: chunks of U levels; the next chunk's 2*U row loads are in flight while
         // the current chunk is processed
         double na[U][V], nb[U][V];
@@ -1172,7 +1173,9 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                 if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
             }
         }
-        auto sx1 = [&](int i) -> double { return (i == ksfc) ? lnps : s_lnp[i]; };      // modified axis
+        // modified axis: unconditional LDS read + select (the compiler otherwise wraps the read in a divergent branch;
+        // the empty asm keeps the load where it is; 8 of 82 exec-mask regions of the loop gone, 2.28 -> 2.25 ms)
+        auto sx1 = [&](int i) -> double { double v = s_lnp[i]; asm("" : "+v"(v)); return (i == ksfc) ? lnps : v; };
         auto is_sfc = [&](int i) -> bool { return ksfc >= 0 && (i == ksfc || (fill && i > ksfc)); };
         // register caches: source levels (ci, ci+1) of each pair
         int ci1 = -2, ci2 = -2;
@@ -1226,7 +1229,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                 if (l < N) {
                     double pa = s_akm[l] + ps * s_bkm[l];                          // step_03:87-88
                     if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
-                    double x = pgw_log(pa);                                       // functions.py:471
+                    double x = pgw_log_f3(pa);                                       // functions.py:471
                     if (!(x >= xprev)) { j1 = 0; j2 = 0; }
                     while (j1 < S) { double xs = sx1(j1); if (xs == x || xs > x) break; ++j1; }
                     while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
@@ -1755,6 +1758,13 @@ __global__ __launch_bounds__(BLOCK) void k_byteswap(long long n16, long long n, 
 __global__ void k_test_log(long long n, const double *__restrict__ in, double *__restrict__ out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = pgw_log(in[i]);
+}
+
+// pgw_exp and the device library's exp over an array (diagnostic entry pgw_test_exp): out[i] = pgw_exp(in[i]),
+// ref[i] = exp(in[i])
+__global__ void k_test_exp(long long n, const double *__restrict__ in, double *__restrict__ out, double *__restrict__ ref) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[i] = pgw_exp(in[i]); ref[i] = exp(in[i]); }
 }
 
 // SharedDivisor over arrays (diagnostic entry pgw_test_shared_div; tests compare it with IEEE division)

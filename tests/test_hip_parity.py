@@ -787,3 +787,28 @@ def test_shared_divisor_is_ieee_division():
     with np.errstate(all='ignore'):
         want = num / den
     np.testing.assert_array_equal(got, want)          # equal doubles = equal bits, up to the sign of a zero quotient and NaN payloads
+
+
+def test_device_exp_is_library_exp():
+    """pgw_exp (explicit-FMA restatement of the device library's exp, used by every e_sat evaluation) gives the
+    library's bits over the arguments of the path and far beyond, incl. overflow / underflow / NaN / inf, and is
+    within 1 ulp of numpy."""
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(321)
+    x = np.concatenate([rng.uniform(-40, 12, 1 << 20),          # 17.5 (T - T0) / (T - 32), 22.6 (T - T0) / (T + 0.7)
+                        rng.uniform(-760, 720, 1 << 18),
+                        np.array([0.0, -0.0, 1.0, -1.0, 709.78, 709.79, 710.0, 1024.0, 1025.0, -745.0, -745.2, -1075.0, -1076.0,
+                                  np.inf, -np.inf, np.nan, 1e-300, -1e-300, 5e-324])])
+    n = x.size
+    dx = ctx.to_device(x)
+    out, ref = ctx.empty((n,), np.float64), ctx.empty((n,), np.float64)
+    ctx._check(ctx.lib.pgw_test_exp(ctx.handle, n, dx.ptr, out.ptr, ref.ptr))
+    got, lib = out.numpy(), ref.numpy()
+    np.testing.assert_array_equal(got, lib)
+    with np.errstate(all='ignore'):
+        want = np.exp(x)
+    fin = np.isfinite(want) & (want > 1e-300)
+    ulp = np.abs(got[fin] - want[fin]) / np.spacing(want[fin])
+    assert ulp.max() <= 1.0, ulp.max()
+    assert np.isnan(got[np.isnan(x)]).all() and got[x == np.inf][0] == np.inf and got[x == -np.inf][0] == 0.0
