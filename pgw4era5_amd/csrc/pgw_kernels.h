@@ -171,7 +171,7 @@ __device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double tv, double p_
         a.dmin = d; a.kstar = l + 1; a.phi_s = a.phi; a.tv_s = tv; a.lnp_s = a.lnp_lo;
     }
     double p_hi = fix_p(p_top);                       // :135
-    double lnp_hi = pgw_log(p_hi);
+    double lnp_hi = pgw_log_f3(p_hi);                   // the log of the level loops of geopot / phi_ref / pass kernels
     a.phi = a.phi + (CON_RD * tv) * (a.lnp_lo - lnp_hi);   // :149-152, dlnpa :136-138
     a.p_lo = p_hi; a.lnp_lo = lnp_hi;
 }
