@@ -192,7 +192,7 @@ __device__ __forceinline__ double pgw_exp(double x) {
     const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
     double r = __builtin_fma(-0x1.62e42fefa39efp-1, n, x);
     r = __builtin_fma(-0x1.abc9e3b39803fp-56, n, r);
-    double p = __builtin_fma(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
+    double p = fma3(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
     p = fma3(r, p, 0x1.71dee623fde64p-19);
     p = fma3(r, p, 0x1.a01997c89e6b0p-16);
     p = fma3(r, p, 0x1.a01a014761f6ep-13);
