@@ -765,6 +765,9 @@ static int side_stream_env() {
     return (e && e[0] == '1') ? 1 : 0;
 }
 
+#ifndef QUAD_U
+#define QUAD_U 2          // levels per software-pipeline chunk of k_delta_quad
+#endif
 #ifndef PGW_LOOP_DEFAULT
 #define PGW_LOOP_DEFAULT 0
 #endif
@@ -1204,13 +1207,13 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                     // arrays below 4 GiB (a 0.25 deg L137 field is 1.1 GB): 32-bit byte offsets from uniform bases
                     const bool o32 = (unsigned long long)ntime * (N > S ? N : S) * ncol * sizeof(T) < (1ull << 32);
 if (o32)
-                        hipLaunchKernelGGL((k_delta_quad<T, 2, 128, boff32>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
+                        hipLaunchKernelGGL((k_delta_quad<T, QUAD_U, 128, boff32>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
                                            ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV,
                                            (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, dwd, check_top,
                                            (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out,
                                            (T *)a->QV_out, qv_done, ctx->d_status);
                     else
-                        hipLaunchKernelGGL((k_delta_quad<T, 2, 128, boff64>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
+                        hipLaunchKernelGGL((k_delta_quad<T, QUAD_U, 128, boff64>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
                                            ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV,
                                            (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, dwd, check_top,
                                            (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out,
