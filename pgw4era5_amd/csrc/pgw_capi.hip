@@ -1196,6 +1196,12 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
             if ((rc = status_reset(ctx))) return rc;
             {
                 Prof pr(ctx, PGW_K_QUAD_DELTA);
+#define LAUNCH_QUAD(OT, LERP_)                                                                                        \
+                    hipLaunchKernelGGL((k_delta_quad<T, QUAD_U, 128, OT, LERP_>), dim3(nblocks((long long)ntime * ncol, 128)), \
+                                       dim3(128), qlds, ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T,     \
+                                       (const T *)a->QV, (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, \
+                                       dwd, check_top, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out,      \
+                                       (T *)a->V_out, (T *)a->QV_out, qv_done, ctx->d_status)
                 DISPATCH_T(dtype, {
                     PairSrc<T> dth{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
                                    {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
@@ -1206,19 +1212,11 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                                    {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
                     // arrays below 4 GiB (a 0.25 deg L137 field is 1.1 GB): 32-bit byte offsets from uniform bases
                     const bool o32 = (unsigned long long)ntime * (N > S ? N : S) * ncol * sizeof(T) < (1ull << 32);
-if (o32)
-                        hipLaunchKernelGGL((k_delta_quad<T, QUAD_U, 128, boff32>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
-                                           ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV,
-                                           (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, dwd, check_top,
-                                           (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out,
-                                           (T *)a->QV_out, qv_done, ctx->d_status);
-                    else
-                        hipLaunchKernelGGL((k_delta_quad<T, QUAD_U, 128, boff64>), dim3(nblocks((long long)ntime * ncol, 128)), dim3(128), qlds,
-                                           ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T, (const T *)a->QV,
-                                           (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, dwd, check_top,
-                                           (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out, (T *)a->V_out,
-                                           (T *)a->QV_out, qv_done, ctx->d_status);
+                    // LERP: the instant lies between two records (false: it is a record, `exact`)
+                    if (o32) { if (exact) LAUNCH_QUAD(boff32, false); else LAUNCH_QUAD(boff32, true); }
+                    else { if (exact) LAUNCH_QUAD(boff64, false); else LAUNCH_QUAD(boff64, true); }
                 });
+#undef LAUNCH_QUAD
             }
             HIPCHK(ctx, hipGetLastError());
             if (!defer) {

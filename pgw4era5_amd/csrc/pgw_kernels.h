@@ -743,10 +743,12 @@ struct DeltaSrc {
     }
     // same, addressed by byte offset (ld_off); the division by the kernel-wide x_hi goes through a reciprocal the
     // caller computed once (SharedDivisor: same quotient bits)
-    template <typename O>
+    // LERP is the compile-time form of `a != nullptr` (all records of a file share the instant, so it is one
+    // property of the launch): no per-source null test - those tests were uniform 64-bit masks kept in spilled SGPRs
+    template <bool LERP, typename O>
     __device__ __forceinline__ double get_at(O byte_off, const SharedDivisor &by_x_hi) const {
         double vb = (double)ld_off(b, byte_off);
-        if (!a) return vb;
+        if (!LERP) return vb;
         double va = (double)ld_off(a, byte_off);
         return by_x_hi.divide(va - vb) * x_new + vb;
     }
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
 #ifndef QUAD_MINW
 #define QUAD_MINW 3
 #endif
-template <typename T, int U, int TPB, typename O>
+template <typename T, int U, int TPB, typename O, bool LERP>
 __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                        const T *__restrict__ fT, const T *__restrict__ fQ,
                                                        const T *__restrict__ fU, const T *__restrict__ fV,
@@ -1185,22 +1187,22 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
             if (ci1 == i1) return;
             O o = dbase + (O)(S - 1 - i1) * row;
             if (ci1 + 1 == i1) { a_lo = a_hi; b_lo = b_hi; }
-            else { a_lo = is_sfc(i1) ? sfa : sTa.get_at(o, by_x_hi); b_lo = is_sfc(i1) ? sfb : sHur.get_at(o, by_x_hi); }
+            else { a_lo = is_sfc(i1) ? sfa : sTa.template get_at<LERP>(o, by_x_hi); b_lo = is_sfc(i1) ? sfb : sHur.template get_at<LERP>(o, by_x_hi); }
             int ih = (i1 + 1 < S) ? i1 + 1 : i1;
             O oh = dbase + (O)(S - 1 - ih) * row;
-            a_hi = is_sfc(ih) ? sfa : sTa.get_at(oh, by_x_hi);
-            b_hi = is_sfc(ih) ? sfb : sHur.get_at(oh, by_x_hi);
+            a_hi = is_sfc(ih) ? sfa : sTa.template get_at<LERP>(oh, by_x_hi);
+            b_hi = is_sfc(ih) ? sfb : sHur.template get_at<LERP>(oh, by_x_hi);
             ci1 = i1;
         };
         auto fetch2 = [&](int i1) {
             if (ci2 == i1) return;
             O o = dbase + (O)(S - 1 - i1) * row;
             if (ci2 + 1 == i1) { c_lo = c_hi; d_lo = d_hi; }
-            else { c_lo = sUa.get_at(o, by_x_hi); d_lo = sVa.get_at(o, by_x_hi); }
+            else { c_lo = sUa.template get_at<LERP>(o, by_x_hi); d_lo = sVa.template get_at<LERP>(o, by_x_hi); }
             int ih = (i1 + 1 < S) ? i1 + 1 : i1;
             O oh = dbase + (O)(S - 1 - ih) * row;
-            c_hi = sUa.get_at(oh, by_x_hi);
-            d_hi = sVa.get_at(oh, by_x_hi);
+            c_hi = sUa.template get_at<LERP>(oh, by_x_hi);
+            d_hi = sVa.template get_at<LERP>(oh, by_x_hi);
             ci2 = i1;
         };
         int j1 = 0, j2 = 0;
