@@ -25,6 +25,7 @@ def main():
     p.add_argument('--nlon', type=int, default=1440)
     p.add_argument('--nlev', type=int, default=137)
     p.add_argument('--dir', default='/tmp/pgw_e2e')
+    p.add_argument('--ranks', type=int, default=1, help='worker processes (-p); > 1: only the pipelined total is timed')
     a = p.parse_args()
     import numpy as np
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3, settings as S
@@ -40,7 +41,16 @@ def main():
     size = os.path.getsize(os.path.join(a.dir, 'era', S.era5_file_name_base.format(first)))
     last = first + dt.timedelta(hours=a.files - 1)
     argv = ['-i', os.path.join(a.dir, 'era'), '-o', os.path.join(a.dir, 'out'), '-d', os.path.join(a.dir, 'deltas'),
-            '-f', first.strftime('%Y%m%d%H'), '-l', last.strftime('%Y%m%d%H'), '-H', '1', '-p', '1', '-t']
+            '-f', first.strftime('%Y%m%d%H'), '-l', last.strftime('%Y%m%d%H'), '-H', '1', '-p', str(a.ranks), '-t']
+    if a.ranks > 1:                       # workers are separate processes: time the whole command only
+        t0 = time.time()
+        n_iter = s3._cli(argv)
+        t_pipe = time.time() - t0
+        print(json.dumps(dict(files=a.files, ranks=a.ranks, file_GB=round(size / 1e9, 3), n_iter=n_iter,
+                              total_s=round(t_pipe, 2), s_per_file=round(t_pipe / a.files, 3),
+                              note='includes process start, delta upload and pinning in every rank')))
+        shutil.rmtree(a.dir, ignore_errors=True)
+        return
     t0 = time.time()
     s3.load_delta_set(s3.default_context(), os.path.join(a.dir, 'deltas'), np.float32)      # once per run
     t_deltas = time.time() - t0
