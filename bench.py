@@ -167,8 +167,8 @@ def main():
         n_pure = 0
         while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
             n_pure += 1
-        # pure-pressure levels: their final QV is written by k_delta_quad (fp64 storage, stop-above-p_ref passes)
-        quad = a.storage == 'f64' and not a.full_column and os.environ.get('PGW_QUAD', '1') != '0'
+        # pure-pressure levels: their final QV is written by k_delta_quad (stop-above-p_ref passes)
+        quad = not a.full_column and os.environ.get('PGW_QUAD', '1') != '0'
         kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0)
         kern = {}
         for k, (cnt, ms) in prof.items():

@@ -1188,8 +1188,10 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                            ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
                            ctx->d_status);                                                                             \
     } while (0)
-        // fp32 storage: both pairs are VALU bound and the 3-waves/SIMD quad kernel measured slower (2.62 vs 2.49 ms)
-        if (quad_env() && dtype == PGW_F64 && !(!check_top && side_stream_env())) {
+        // both storage types: with fp32 storage the quad kernel was slower than the two pair kernels at first (2.62 vs
+        // 2.49 ms); after the instruction trims it is faster there too (2.28 vs 2.38 ms, and the finalize kernel skips
+        // the pure-pressure levels: 0.14 vs 0.21 ms)
+        if (quad_env() && !(!check_top && side_stream_env())) {
             // ---- all four variables in one kernel
             const size_t qlds = (size_t)2 * N * sizeof(double);
             qv_done = full_column_env() ? 0 : ctx->n_pure;     // full-column passes read e at every level
