@@ -1233,49 +1233,59 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                     if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
                     double x = pgw_log_f3(pa);                                       // functions.py:471
                     if (!(x >= xprev)) { j1 = 0; j2 = 0; }
-                    while (j1 < S) { double xs = sx1(j1); if (xs == x || xs > x) break; ++j1; }
                     while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
                     xprev = (x == x) ? x : __builtin_inf();
-                    // ta, hur on the modified axis
+                    // ua, va on the plain plev axis
+                    double dc, dd;
+                    int p1, p2;                                                    // its bracket
+                    if (j2 >= S) { p1 = p2 = S - 1; }                              // above range, constant :558-560
+                    else {
+                        double xs = s_lnp[j2];
+                        if (xs == x) { p1 = p2 = j2; }                             // exact                 :540-543
+                        else if (j2 == 0) { p1 = p2 = 0; }                         // below range, constant :534-536
+                        else { p1 = j2 - 1; p2 = j2; }                             // bracket               :545-548
+                    }
+                    fetch2(p1);
+                    dc = c_lo; dd = d_lo;
+                    double dxp = 0.0;
+                    SharedDivisor by_Dp(1.0, 1.0);
+                    if (p1 != p2) {                                                // :575-578
+                        double x1 = s_lnp[p1], x2 = s_lnp[p2];
+                        dxp = x - x1;
+                        by_Dp = SharedDivisor(x2 - x1);                            // x1 < x < x2: finite, positive
+                        dc = c_lo + by_Dp.divide(dxp * (c_hi - c_lo));
+                        dd = d_lo + by_Dp.divide(dxp * (d_hi - d_lo));
+                    }
+                    // ta, hur on the axis modified by the surface insertion (level ksfc moved to ps_hist, :362-365).
+                    // Source levels below index ksfc are untouched, so while the plain scan stands at j2 < ksfc the
+                    // modified scan stands there too (same values, same rule): same bracket, same x - x1, same divisor.
                     double da, db;
-                    {
+                    if (ksfc < 0 || j2 < ksfc) {
+                        fetch1(p1);
+                        da = a_lo; db = b_lo;
+                        if (p1 != p2) {
+                            da = a_lo + by_Dp.divide(dxp * (a_hi - a_lo));
+                            db = b_lo + by_Dp.divide(dxp * (b_hi - b_lo));
+                        }
+                    } else {
+                        // j1 may lag behind (it only moves here); targets ascend, so resuming from it finds the same index
+                        while (j1 < S) { double xs = sx1(j1); if (xs == x || xs > x) break; ++j1; }
                         int i1, i2;
-                        if (j1 >= S) { i1 = i2 = S - 1; }                          // above range, constant :558-560
+                        if (j1 >= S) { i1 = i2 = S - 1; }
                         else {
                             double xs = sx1(j1);
-                            if (xs == x) { i1 = i2 = j1; }                         // exact                 :540-543
-                            else if (j1 == 0) { i1 = i2 = 0; }                     // below range, constant :534-536
-                            else { i1 = j1 - 1; i2 = j1; }                         // bracket               :545-548
+                            if (xs == x) { i1 = i2 = j1; }
+                            else if (j1 == 0) { i1 = i2 = 0; }
+                            else { i1 = j1 - 1; i2 = j1; }
                         }
                         fetch1(i1);
                         da = a_lo; db = b_lo;
-                        if (i1 != i2) {                                            // :575-578
+                        if (i1 != i2) {
                             double x1 = sx1(i1), x2 = sx1(i2);
                             const double dx = x - x1;
-                            const SharedDivisor by_Dx(x2 - x1);                    // x1 < x < x2: finite, positive
+                            const SharedDivisor by_Dx(x2 - x1);
                             da = a_lo + by_Dx.divide(dx * (a_hi - a_lo));
                             db = b_lo + by_Dx.divide(dx * (b_hi - b_lo));
-                        }
-                    }
-                    // ua, va on the plain plev axis
-                    double dc, dd;
-                    {
-                        int i1, i2;
-                        if (j2 >= S) { i1 = i2 = S - 1; }
-                        else {
-                            double xs = s_lnp[j2];
-                            if (xs == x) { i1 = i2 = j2; }
-                            else if (j2 == 0) { i1 = i2 = 0; }
-                            else { i1 = j2 - 1; i2 = j2; }
-                        }
-                        fetch2(i1);
-                        dc = c_lo; dd = d_lo;
-                        if (i1 != i2) {
-                            double x1 = s_lnp[i1], x2 = s_lnp[i2];
-                            const double dx = x - x1;
-                            const SharedDivisor by_Dx(x2 - x1);
-                            dc = c_lo + by_Dx.divide(dx * (c_hi - c_lo));
-                            dd = d_lo + by_Dx.divide(dx * (d_hi - d_lo));
                         }
                     }
                     const O o = base + (O)l * row;
