@@ -1193,7 +1193,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         // the pure-pressure levels: 0.14 vs 0.21 ms)
         if (quad_env() && !(!check_top && side_stream_env())) {
             // ---- all four variables in one kernel
-            const size_t qlds = (size_t)2 * N * sizeof(double);
+            const size_t qlds = (size_t)3 * N * sizeof(double);
             qv_done = full_column_env() ? 0 : ctx->n_pure;     // full-column passes read e at every level
             if ((rc = status_reset(ctx))) return rc;
             {
@@ -1203,7 +1203,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                                        dim3(128), qlds, ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T,     \
                                        (const T *)a->QV, (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, \
                                        dwd, check_top, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out,      \
-                                       (T *)a->V_out, (T *)a->QV_out, qv_done, ctx->d_status)
+                                       (T *)a->V_out, (T *)a->QV_out, qv_done, ctx->n_pure, ctx->d_status)
                 DISPATCH_T(dtype, {
                     PairSrc<T> dth{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
                                    {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};

@@ -1123,18 +1123,24 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                                                        PairSrc<T> dth, PairSrc<T> dsfc, DeltaSrc<T> psh, PairSrc<T> dw,
                                                        int check_top, T *__restrict__ oT, T *__restrict__ oE,
                                                        T *__restrict__ oHur, T *__restrict__ oU, T *__restrict__ oV,
-                                                       T *__restrict__ oQ, int n_pure, DevStatus *st) {
+                                                       T *__restrict__ oQ, int n_pure, int n_pure_lv, DevStatus *st) {
     // n_pure > 0: the first n_pure full levels are pure-pressure levels (bkm == 0): their pressure does not depend
     // on the surface pressure, so the final QV = e_to_q(e, akm) (step_03:262-266,370) is written here already
     // (instead of e, which only the levels below p_ref and k_finalize_ps_hus need) and the finalize kernel skips them.
-    extern __shared__ double lds_quad[];            // akm[N] | bkm[N]
+    // n_pure_lv: number of leading pure-pressure levels (n_pure is 0 when the QV shortcut is off); their pressure akm[l]
+    // is the same in every column, so ln(akm[l]) is taken once per block instead of once per column and level
+    extern __shared__ double lds_quad[];            // akm[N] | bkm[N] | ln(akm)[N] (first n_pure_lv entries)
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
     __shared__ double s_lnp[MAX_PLEV];
     const int S = pt.n;
-    double *s_akm = lds_quad, *s_bkm = lds_quad + lv.nlev;
+    double *s_akm = lds_quad, *s_bkm = lds_quad + lv.nlev, *s_lnpa = lds_quad + 2 * lv.nlev;
     for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
-    for (int i = threadIdx.x; i < lv.nlev; i += TPB) { s_akm[i] = lv.akm[i]; s_bkm[i] = lv.bkm[i]; }
+    for (int i = threadIdx.x; i < lv.nlev; i += TPB) {
+        const double am = lv.akm[i];
+        s_akm[i] = am; s_bkm[i] = lv.bkm[i];
+        if (i < n_pure_lv) s_lnpa[i] = pgw_log_f3(am);
+    }
     __syncthreads();
     long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
     double min_t = __builtin_inf(), min_s = __builtin_inf();
@@ -1153,6 +1159,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
         const O dbase = (O)((unsigned long long)(t * S * ncol + c) * sizeof(T));
         const O base = (O)((unsigned long long)(t * N * ncol + c) * sizeof(T));
         const double ps = (double)PS[flat];
+        const bool ps_finite = __builtin_fabs(ps) <= 1.7976931348623157e308;   // false for NaN, +-inf
         // ---- surface insertion for ta / hur (replace_delta_sfc, functions.py:343-366)
         int ksfc = -1;
         bool fill = false;
@@ -1231,7 +1238,9 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                 if (l < N) {
                     double pa = s_akm[l] + ps * s_bkm[l];                          // step_03:87-88
                     if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
-                    double x = pgw_log_f3(pa);                                       // functions.py:471
+                    double x;                                                      // functions.py:471
+                    if (l < n_pure_lv) x = ps_finite ? s_lnpa[l] : pa;             // pa == akm[l]; NaN for a non-finite ps
+                    else x = pgw_log_f3(pa);
                     if (!(x >= xprev)) { j1 = 0; j2 = 0; }
                     while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
                     xprev = (x == x) ? x : __builtin_inf();
