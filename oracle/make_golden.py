@@ -9,6 +9,7 @@ succeeds; only functions that touch none of them are called.  Nothing of the ref
 
 usage:  python oracle/make_golden.py            (writes tests/golden/ref_leaf_vectors.npz)
         python oracle/make_golden.py harmonic   (writes tests/golden/ref_harmonic_vectors.npz only)
+        python oracle/make_golden.py f32        (writes tests/golden/ref_leaf_f32_vectors.npz only)
 """
 import os
 import sys
@@ -193,8 +194,64 @@ def harmonic():
     print('wrote', len(out), 'arrays;', meta)
 
 
+def leaf_f32():
+    """The same leaf functions on float32 inputs mixed with float64 ones, as they meet on float32 ERA5 files
+    (decode_cf=False, step_03:60): pins where numpy's promotion puts float32 arithmetic (oracle/pgw_oracle_refdtype.py).
+    Values AND result dtypes are recorded.  Run with this container's numpy (2.2, NEP 50); the reference pins numpy
+    1.23.5 - both give float32 for `python float (op) float32 array`, the only mixed case these functions contain."""
+    F = import_reference_functions()
+    rng = np.random.default_rng(20261006)
+    out, meta = {}, {'numpy': np.__version__}
+    f32 = np.float32
+    ta = np.concatenate([np.array([180., 250.16, 250.17, 260., 273.15, 273.16, 273.17, 300., 320.]),
+                         rng.uniform(185., 315., 55)]).astype(f32)
+    pa = np.concatenate([np.array([1., 100., 5000., 30000., 50000., 70000., 85000., 101325., 105000.]),
+                         rng.uniform(1., 105000., 55)])
+    hus = np.concatenate([np.array([0., 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 5e-3, 1e-2, 3e-2]),
+                          rng.uniform(0, 2.5e-2, 55)]).astype(f32)
+    out['hum_ta'] = ta; out['hum_pa'] = pa; out['hum_hus'] = hus
+    out['hum_e'] = F.specific_humidity_to_vapor_pressure(hus, pa)              # float32 hus, float64 pa
+    out['hum_e_allf32'] = F.specific_humidity_to_vapor_pressure(hus, pa.astype(f32))
+    out['hum_q_from_e'] = F.vapor_pressure_to_specific_humidity(out['hum_e'], pa)
+    out['hum_esat_water'] = F.saturation_vapor_pressure_water_or_ice(pa, ta, water=True)
+    out['hum_esat_ice'] = F.saturation_vapor_pressure_water_or_ice(pa, ta, water=False)
+    # interp_extrap_1d: float32 values on float64 abscissae (a delta that needed no time interpolation, functions.py:282-283)
+    ncase, S, N = 24, 9, 23
+    sx = np.empty((ncase, S)); sy = np.empty((ncase, S), dtype=f32); tx = np.empty((ncase, N))
+    for c in range(ncase):
+        sx[c] = np.log(np.sort(rng.uniform(50., 101000., S)))
+        sy[c] = rng.normal(0, 3, S).astype(f32)
+        tx[c] = np.log(np.sort(rng.uniform(10., 108000., N)))
+    out['int_src_x'] = sx; out['int_src_y'] = sy; out['int_targ_x'] = tx
+    for mode in ['constant', 'linear']:
+        out['int_' + mode] = np.stack([F.interp_extrap_1d(sx[c], sy[c], tx[c], mode) for c in range(ncase)])
+    # replace_delta_sfc keeps the dtype of the delta
+    plev = np.array([100, 1000, 5000, 10000, 25000, 50000, 70000, 85000, 92500, 100000.])
+    d0 = rng.normal(0, 1, len(plev)).astype(f32)
+    ps_cases = np.array([101300., 92500., 90000., 60000.], dtype=f32)
+    res = [F.replace_delta_sfc(plev, ps, d0, f32(9.25)) for ps in ps_cases]
+    out['rds_plev'] = plev; out['rds_delta'] = d0; out['rds_ps'] = ps_cases
+    out['rds_out_P'] = np.stack([r[0] for r in res]); out['rds_out_D'] = np.stack([r[1] for r in res])
+    # integrate_tos: float32 land / ice fractions of the ERA5 file with float64 (time-interpolated) deltas, and all float32
+    shp = (6, 7)
+    tos = rng.normal(1.5, 0.5, shp); tos[rng.uniform(size=shp) < 0.3] = np.nan
+    ts = rng.normal(2.5, 0.5, shp)
+    land = np.clip(rng.uniform(-0.3, 1.3, shp), 0, 1).astype(f32)
+    ice = np.clip(rng.uniform(-0.5, 1.0, shp), 0, 1).astype(f32); ice[rng.uniform(size=shp) < 0.25] = np.nan
+    out['tos_tos'] = tos; out['tos_ts'] = ts; out['tos_land'] = land; out['tos_ice'] = ice
+    out['tos_out'] = F.integrate_tos(tos.copy(), ts.copy(), land.copy(), ice.copy())
+    out['tos_out_allf32'] = F.integrate_tos(tos.astype(f32), ts.astype(f32), land.copy(), ice.copy())
+    meta['dtypes'] = {k: str(v.dtype) for k, v in out.items()}
+    np.savez_compressed(os.path.join(OUT, 'ref_leaf_f32_vectors.npz'), **out)
+    with open(os.path.join(OUT, 'ref_leaf_f32_vectors.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('wrote', len(out), 'arrays;', meta)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'harmonic':
         harmonic()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'f32':
+        leaf_f32()
     else:
         main()
