@@ -106,11 +106,11 @@ def main():
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
     from pgw4era5_amd.device import Context
 
-    if a.full_column:
-        os.environ['PGW_FULL_COLUMN'] = '1'
     dtype = np.float64 if a.storage == 'f64' else np.float32
     s = np.dtype(dtype).itemsize
     ctx = Context(local)
+    if a.full_column:
+        ctx.set_option('full_column', 1)
     from pgw4era5_amd import device as _device
     _device._default = ctx                 # the functions.py mirror uses the process-wide context
     t0 = time.time()
@@ -168,7 +168,7 @@ def main():
         while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
             n_pure += 1
         # pure-pressure levels: their final QV is written by k_delta_quad (stop-above-p_ref passes)
-        quad = not a.full_column and os.environ.get('PGW_QUAD', '1') != '0'
+        quad = not a.full_column and ctx.get_option('quad') != 0
         kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0)
         kern = {}
         for k, (cnt, ms) in prof.items():

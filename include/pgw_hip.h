@@ -64,12 +64,26 @@ enum pgw_kernel_id {
     PGW_K_BYTESWAP = 15, PGW_K_HARMONIC = 16, PGW_K_COUNT = 17
 };
 
+/* per-context options (pgw_set_option).  Defaults come from the environment variables named below, which are read
+ * ONCE, in pgw_ctx_create; nothing on the launch path calls getenv. */
+enum pgw_option {
+    PGW_OPT_QUAD = 0,         /* 1 (default): ta+hur and ua+va deltas in one kernel; 0: the two pair kernels   [PGW_QUAD]        */
+    PGW_OPT_FULL_COLUMN = 1,  /* 1: loop passes read every level (input-independent traffic); default 0: a wave stops once
+                                 all its columns are above p_ref                                                 [PGW_FULL_COLUMN] */
+    PGW_OPT_FORCE_VEC1 = 2,   /* 1: one column per thread everywhere (test knob for the scalar-column code path)  [PGW_FORCE_VEC1]  */
+    PGW_OPT_MULTIPASS = 3,    /* 1 (default): several passes of the surface-pressure loop per launch with the column held
+                                 on chip; 0: one launch per pass                                                 [PGW_MULTIPASS]   */
+    PGW_OPT_COUNT = 4
+};
+
 /* ---------------------------------------------------------------- context ------------ */
 /* One context = one HIP device + one stream; replaces the implicit per-process state of a
  * reference worker (parallel.py:18-32: one process per file, no shared state). */
 int pgw_device_count(int *n);
 int pgw_ctx_create(int device, pgw_ctx **out);
 int pgw_ctx_destroy(pgw_ctx *ctx);
+int pgw_set_option(pgw_ctx *ctx, int option, int value);
+int pgw_get_option(pgw_ctx *ctx, int option, int *value);
 const char *pgw_last_error(pgw_ctx *ctx);
 long long pgw_error_column(pgw_ctx *ctx);
 const char *pgw_version(void);

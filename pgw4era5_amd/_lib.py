@@ -25,6 +25,9 @@ KERNEL_IDS = dict(pressure=0, q_to_rh=1, rh_to_q=2, integ_geopot=3, interp_logp=
                   vert_interp_delta=6, adjust_ps_step=7, regrid=8, surface=9, finalize=10,
                   thermo_delta=11, wind_delta=12, phi_ref_hybrid=13, quad_delta=14, byteswap=15, harmonic=16)
 
+# enum pgw_option (include/pgw_hip.h)
+OPTIONS = dict(quad=0, full_column=1, force_vec1=2, multipass=3)
+
 PGW_OK = 0
 PGW_ERR_HIP = 1
 PGW_ERR_ARG = 2
@@ -40,6 +43,8 @@ SIGNATURES = {
     'pgw_device_count': (_i, [_ip]),
     'pgw_ctx_create': (_i, [_i, C.POINTER(_vp)]),
     'pgw_ctx_destroy': (_i, [_vp]),
+    'pgw_set_option': (_i, [_vp, _i, _i]),
+    'pgw_get_option': (_i, [_vp, _i, _ip]),
     'pgw_last_error': (C.c_char_p, [_vp]),
     'pgw_error_column': (_ll, [_vp]),
     'pgw_version': (C.c_char_p, []),

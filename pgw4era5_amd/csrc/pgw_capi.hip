@@ -18,19 +18,17 @@ struct ProfRec { int kid; hipEvent_t e0, e1; };
 struct pgw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;     // side stream: the HBM-bound wind pair runs beside the VALU-bound ta+hur pair
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    LoopState *h_loop = nullptr;       // pinned ring of 3 read-backs of the device loop state
-    hipEvent_t loop_ev[3] = {nullptr, nullptr, nullptr};
-    LoopMail *mail = nullptr;          // coherent host mailbox polled by the loop (PGW_DEVICE_LOOP=3/4)
     std::string err;
     long long err_col = -1;
     DevStatus *d_status = nullptr;     // device; [1] = alternate block of the loop passes (cleared by the pass before)
     DevStatus *h_status = nullptr;     // pinned host mirror
+    // options (pgw_set_option; defaults from the environment, read ONCE in pgw_ctx_create)
+    int opt[PGW_OPT_COUNT];
     // vertical grid
     int nlev = 0;
     double *d_levels = nullptr;        // ak | bk | akm | bkm
     std::vector<double> h_akm, h_bkm;
+    double h_akN = 0.0, h_bkN = 0.0;   // ak[nlev], bk[nlev] (surface half level)
     double ps_mono_min = 0.0;
     int n_pure = 0;                    // leading full levels with bkm == 0 (pure-pressure levels)
     // plev table cache for vert_interp_delta
@@ -89,7 +87,9 @@ static const char *status_text(int code) {
                    "the data beyond to upper-most pressure level of the climate delta, you can set the flag "
                    "--ignore_top_pressure_error and re-run the script.";
         case PGW_ERR_NOT_CONVERGED: return "ERROR! Pressure adjustment did not converge";
-        case PGW_ERR_GRID_EXTENT: return "ERA5 dataset extends further than GCM dataset!";
+        case PGW_ERR_GRID_EXTENT:      // functions.py:845-856 / 877-888 ("North or South" / "East or West" is chosen by the host)
+            return "ERA5 dataset extends further than GCM dataset!. Perhaps consider using ERA5 on a subdomain only if "
+                   "global coverage is not required?";
         case PGW_ERR_NO_P_REF:
             return "No reference pressure level above the required local minimum pressure level could not be found "
                    "everywhere. This is likely the case because your geopotential data set does not reach up high enough "
@@ -104,18 +104,19 @@ struct Prof {
     hipEvent_t take() {
         hipEvent_t e = nullptr;
         if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
-        else hipEventCreate(&e);
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;      // launch goes unprofiled (see ~Prof)
         return e;
     }
     hipStream_t st;
     Prof(pgw_ctx *c_, int kid_, hipStream_t st_ = nullptr) : c(c_), kid(kid_), st(st_ ? st_ : c_->stream) {
         if (c->prof_on) {
             e0 = take(); e1 = take();
-            hipEventRecord(e0, st);
+            if (e0 && e1) hipEventRecord(e0, st);
+            else { if (e0) c->event_pool.push_back(e0); if (e1) c->event_pool.push_back(e1); e0 = e1 = nullptr; }
         }
     }
     ~Prof() {
-        if (c->prof_on) {
+        if (e0 && e1) {
             hipEventRecord(e1, st);
             c->prof_pending.push_back({kid, e0, e1});
         }
@@ -125,7 +126,6 @@ struct Prof {
 static int prof_resolve(pgw_ctx *ctx) {
     if (ctx->prof_pending.empty()) return PGW_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto &r : ctx->prof_pending) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.e0, r.e1);
@@ -143,11 +143,10 @@ static inline bool aligned16(const void *p) { return p == nullptr || (((uintptr_
 
 // columns per thread: 16 B per lane when shape and alignment allow, else 1
 // `max_v` caps the width for kernels whose register footprint makes the widest form slower.
-static int pick_vec(int dtype, long long ncol, std::initializer_list<const void *> ptrs, int max_v = 4) {
+static int pick_vec(pgw_ctx *ctx, int dtype, long long ncol, std::initializer_list<const void *> ptrs, int max_v = 4) {
     int v = (dtype == PGW_F64) ? 2 : 4;
     if (v > max_v) v = max_v;
-    const char *force = getenv("PGW_FORCE_VEC1");       // tuning knob: scalar columns per thread
-    if (force && force[0] == '1') return 1;
+    if (ctx->opt[PGW_OPT_FORCE_VEC1]) return 1;          // test knob: scalar columns per thread
     for (const void *p : ptrs) if (!aligned16(p)) return 1;
     while (v > 1 && ncol % v != 0) v >>= 1;
     return v;
@@ -213,6 +212,12 @@ extern "C" int pgw_device_count(int *n) {
     return PGW_OK;
 }
 
+static int env_flag(const char *name, int dflt) {
+    const char *e = getenv(name);
+    if (!e || !e[0]) return dflt;
+    return (e[0] == '0') ? 0 : 1;
+}
+
 extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
     if (!out) return PGW_ERR_ARG;
     *out = nullptr;
@@ -224,19 +229,17 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
     c->device = device;
     memset(c->prof_count, 0, sizeof(c->prof_count));
     memset(c->prof_ms, 0, sizeof(c->prof_ms));
+    // the environment is read here and nowhere else (no getenv on the launch path)
+    c->opt[PGW_OPT_QUAD] = env_flag("PGW_QUAD", 1);
+    c->opt[PGW_OPT_FULL_COLUMN] = env_flag("PGW_FULL_COLUMN", 0);
+    c->opt[PGW_OPT_FORCE_VEC1] = env_flag("PGW_FORCE_VEC1", 0);
+    c->opt[PGW_OPT_MULTIPASS] = env_flag("PGW_MULTIPASS", 1);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc(&c->h_loop, 3 * sizeof(LoopState)) != hipSuccess ||
-        hipEventCreateWithFlags(&c->loop_ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->loop_ev[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->loop_ev[2], hipEventDisableTiming) != hipSuccess ||
         hipMalloc(&c->d_status, 2 * sizeof(DevStatus)) != hipSuccess ||
         hipHostMalloc(&c->h_status, sizeof(DevStatus)) != hipSuccess ||
         hipMalloc(&c->d_small, SMALL_BYTES) != hipSuccess ||
         hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
-        delete c;
+        pgw_ctx_destroy(c);            // releases whatever was created before the failure
         return PGW_ERR_HIP;
     }
     *out = c;
@@ -246,7 +249,7 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
 extern "C" int pgw_ctx_destroy(pgw_ctx *ctx) {
     if (!ctx) return PGW_OK;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (auto &r : ctx->prof_pending) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
     for (auto &e : ctx->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 8; ++i) if (ctx->ws[i]) hipFree(ctx->ws[i]);
@@ -256,14 +259,21 @@ extern "C" int pgw_ctx_destroy(pgw_ctx *ctx) {
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->t0) hipEventDestroy(ctx->t0);
     if (ctx->t1) hipEventDestroy(ctx->t1);
-    if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
-    if (ctx->fork_ev) hipEventDestroy(ctx->fork_ev);
-    if (ctx->join_ev) hipEventDestroy(ctx->join_ev);
-    for (int i = 0; i < 3; ++i) if (ctx->loop_ev[i]) hipEventDestroy(ctx->loop_ev[i]);
-    if (ctx->h_loop) hipHostFree(ctx->h_loop);
-    if (ctx->mail) hipHostFree(ctx->mail);
-    hipStreamDestroy(ctx->stream);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return PGW_OK;
+}
+
+extern "C" int pgw_set_option(pgw_ctx *ctx, int option, int value) {
+    if (!ctx) return PGW_ERR_ARG;
+    if (option < 0 || option >= PGW_OPT_COUNT) return fail(ctx, PGW_ERR_ARG, "pgw_set_option: unknown option %d", option);
+    ctx->opt[option] = value;
+    return PGW_OK;
+}
+extern "C" int pgw_get_option(pgw_ctx *ctx, int option, int *value) {
+    if (!ctx || !value) return PGW_ERR_ARG;
+    if (option < 0 || option >= PGW_OPT_COUNT) return fail(ctx, PGW_ERR_ARG, "pgw_get_option: unknown option %d", option);
+    *value = ctx->opt[option];
     return PGW_OK;
 }
 
@@ -389,6 +399,7 @@ extern "C" int pgw_set_levels(pgw_ctx *ctx, int nlev, const double *ak, const do
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_levels, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // h is a stack-lifetime buffer
     ctx->nlev = nlev;
+    ctx->h_akN = ak[nlev]; ctx->h_bkN = bk[nlev];
     ctx->ps_mono_min = pmin;
     ctx->n_pure = 0;
     while (ctx->n_pure < nlev && pbkm[ctx->n_pure] == 0.0) ctx->n_pure += 1;
@@ -404,9 +415,11 @@ extern "C" int pgw_get_full_level_coeffs(pgw_ctx *ctx, double *akm_out, double *
     return PGW_OK;
 }
 
+// every compute entry binds the context's device first: a process may hold contexts on several devices
 #define CHECK_COMMON(ctx, dtype, ntime, ncol)                                        \
     NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64"); \
-    NEED(ctx, ntime >= 1 && ncol >= 1, "ntime and ncol must be positive");
+    NEED(ctx, ntime >= 1 && ncol >= 1, "ntime and ncol must be positive");           \
+    HIPCHK(ctx, hipSetDevice(ctx->device));
 
 // dispatch on storage dtype and vector width
 #define DISPATCH_TV(dtype, vec, ...)                                        \
@@ -433,7 +446,7 @@ extern "C" int pgw_pressure_levels(pgw_ctx *ctx, int dtype, int ntime, long long
     CHECK_COMMON(ctx, dtype, ntime, ncol);
     NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
     NEED(ctx, ps && (pa_hl || pa), "null pointer");
-    int vec = pick_vec(dtype, ncol, {ps, pa_hl, pa});
+    int vec = pick_vec(ctx, dtype, ncol, {ps, pa_hl, pa});
     Levels lv = levels_of(ctx);
     {
         Prof pr(ctx, PGW_K_PRESSURE);
@@ -450,7 +463,7 @@ static int humidity_flat(pgw_ctx *ctx, int kid, int dtype, long long n, const vo
                          const void *ta, void *out) {
     NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
     NEED(ctx, n >= 1 && x && pa && ta && out, "bad argument");
-    int vec = pick_vec(dtype, n, {x, pa, ta, out});
+    int vec = pick_vec(ctx, dtype, n, {x, pa, ta, out});
     long long groups = n / vec;
     unsigned int nb = nblocks(groups, BLOCK);
     if (nb > 256 * 16) nb = 256 * 16;
@@ -477,7 +490,7 @@ static int humidity_hybrid(pgw_ctx *ctx, int kid, int dtype, int ntime, long lon
     CHECK_COMMON(ctx, dtype, ntime, ncol);
     NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
     NEED(ctx, x && ps && ta && out, "null pointer");
-    int vec = pick_vec(dtype, ncol, {x, ps, ta, out});
+    int vec = pick_vec(ctx, dtype, ncol, {x, ps, ta, out});
     Levels lv = levels_of(ctx);
     {
         Prof pr(ctx, kid);
@@ -501,7 +514,7 @@ extern "C" int pgw_relative_to_specific_humidity_hybrid(pgw_ctx *ctx, int dtype,
 static int launch_integ_geopot(pgw_ctx *ctx, int dtype, int nlev, int ntime, long long ncol, const void *pa_hl,
                                const void *zgs, const void *ta, const void *hus, double p_ref,
                                const void *p_ref_field, void *phi_ref, int full_column, bool out_f64 = false) {
-    int vec = pick_vec(dtype, ncol, {pa_hl, zgs, ta, hus, p_ref_field, phi_ref});
+    int vec = pick_vec(ctx, dtype, ncol, {pa_hl, zgs, ta, hus, p_ref_field, phi_ref});
     Prof pr(ctx, PGW_K_INTEG_GEOPOT);
 #define LAUNCH_GEO(UU, TO_)                                                                                         \
     DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_integ_geopot<T, V, UU, TO_>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)), \
@@ -532,28 +545,9 @@ template <typename T, int MODE>
 static int launch_interp_mode(pgw_ctx *ctx, int ntime, int S, int N, long long ncol, const T *var, const T *sp,
                               const T *tp, T *out, int logp_in) {
     long long total = (long long)ntime * ncol;
-    const char *ev = getenv("PGW_INTERP_LDS");      // tuning knob: 1 = the LDS-staged variant (first version)
-    if (!(ev && ev[0] == '1')) {
-        Prof pr(ctx, PGW_K_INTERP_LOGP);
-        hipLaunchKernelGGL((k_interp_logp_stream<T, MODE>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream,
-                           ntime, S, N, ncol, var, sp, tp, out, logp_in, ctx->d_status);
-        return PGW_OK;
-    }
-    size_t per_thread = (size_t)2 * S * sizeof(double);
-    int tpb = (per_thread * 256 <= 64 * 1024) ? 256 : (per_thread * 128 <= 64 * 1024) ? 128 : 64;
-    size_t lds = per_thread * tpb;
-    if (lds > 160 * 1024) return fail(ctx, PGW_ERR_ARG, "interp_logp_4d: too many source levels (%d)", S);
     Prof pr(ctx, PGW_K_INTERP_LOGP);
-#define LAUNCH_TPB(TPB)                                                                                            \
-    do {                                                                                                           \
-        if (lds > 64 * 1024)                                                                                       \
-            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_interp_logp<T, MODE, TPB>,                             \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        hipLaunchKernelGGL((k_interp_logp<T, MODE, TPB>), dim3(nblocks(total, TPB)), dim3(TPB), lds, ctx->stream,  \
-                           ntime, S, N, ncol, var, sp, tp, out, logp_in, ctx->d_status);                                    \
-    } while (0)
-    if (tpb == 256) LAUNCH_TPB(256); else if (tpb == 128) LAUNCH_TPB(128); else LAUNCH_TPB(64);
-#undef LAUNCH_TPB
+    hipLaunchKernelGGL((k_interp_logp_stream<T, MODE>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                       ntime, S, N, ncol, var, sp, tp, out, logp_in, ctx->d_status);
     return PGW_OK;
 }
 
@@ -585,7 +579,7 @@ extern "C" int pgw_time_lerp(pgw_ctx *ctx, int dtype, long long n, const void *v
                              double x_hi, double x_new, void *out) {
     NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
     NEED(ctx, n >= 1 && v_before && v_after && out, "bad argument");
-    int vec = pick_vec(dtype, n, {v_before, v_after, out});
+    int vec = pick_vec(ctx, dtype, n, {v_before, v_after, out});
     unsigned int nb = nblocks(n / vec, BLOCK);
     if (nb > 256 * 16) nb = 256 * 16;
     {
@@ -716,24 +710,24 @@ extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int npl
 static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *evap,
                        const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
                        double *delta_ps, double *adj_ps, double p_ref, const double *p_ref_field,
-                       double adj_factor, int full_column, int apply_adj = 1, LoopState *ls = nullptr,
-                       double thresh = 0.0, DevStatus *st = nullptr, DevStatus *clear = nullptr) {
+                       double adj_factor, int full_column, int apply_adj = 1, DevStatus *st = nullptr,
+                       DevStatus *clear = nullptr) {
     if (!st) st = ctx->d_status;
-    int vec = pick_vec(dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field}, 2);
+    int vec = pick_vec(ctx, dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field}, 2);
     // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_ADJUST_PS_STEP);
     DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
                                                 dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
                                                 (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, ls, thresh, clear));
+                                                p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, clear));
     return PGW_OK;
 }
 
 static int launch_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *hus,
                                  const void *PS, const void *FIS, double p_ref, double *phi_out, int full_column,
                                  const double *p_ref_field = nullptr) {
-    int vec = pick_vec(dtype, ncol, {ta, hus, PS, FIS, phi_out}, 2);
+    int vec = pick_vec(ctx, dtype, ncol, {ta, hus, PS, FIS, phi_out}, 2);
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_PHI_REF_HYBRID);
     DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_phi_ref_hybrid<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
@@ -751,74 +745,9 @@ static double max_err_of(pgw_ctx *ctx) {
     return m;
 }
 
-static int quad_env() {
-    // default 1: ta+hur and ua+va in ONE kernel (k_delta_quad); PGW_QUAD=0 -> the two pair kernels
-    const char *e = getenv("PGW_QUAD");
-    return (e && e[0] == '0') ? 0 : 1;
-}
-
-static int side_stream_env() {
-    // PGW_SIDE_STREAM=1: ua+va pair kernel on the context's side stream.  Default 0: measured gain only 1.5 %
-    // (4.96 vs 5.04 ms per file) - either pair kernel alone fills every wave slot, so the two barely co-run -
-    // and the overlapped launches would blur the per-kernel timings.
-    const char *e = getenv("PGW_SIDE_STREAM");
-    return (e && e[0] == '1') ? 1 : 0;
-}
-
 #ifndef QUAD_U
 #define QUAD_U 2          // levels per software-pipeline chunk of k_delta_quad
 #endif
-#ifndef PGW_LOOP_DEFAULT
-#define PGW_LOOP_DEFAULT 0
-#endif
-static int device_loop_env() {
-    // Loop control (fixed p_ref), PGW_DEVICE_LOOP:
-    //   0: the host reads max|err| after every pass (status copy + stream synchronisation) before launching the
-    //      next - the reference's flow literally;
-    //   4: the same flow, but the block that finishes a pass last writes the result to a coherent host mailbox and
-    //      the host polls it (no copy, no synchronisation per pass);
-    //   3: mailbox + one pass ahead: pass k+1 is enqueued before the host has seen pass k; a device-side `done`
-    //      flag turns the single speculated pass after convergence into a no-op;
-    //   2: one pass ahead through a pinned read-back ring (copy + event per pass; measured 4.69 vs 4.55 ms of mode 0);
-    //   1: all max_n_iter passes enqueued back to back (measured slowest: 14 no-op launches per file).
-    const char *e = getenv("PGW_DEVICE_LOOP");
-    if (e && e[0] >= '0' && e[0] <= '4') return e[0] - '0';
-    return PGW_LOOP_DEFAULT;
-}
-
-// wait until the mailbox reports `want` finished passes; gives up when the stream has drained without the report
-static int poll_mail(pgw_ctx *ctx, unsigned int want) {
-    LoopMail *m = ctx->mail;
-    for (unsigned long long spins = 1;; ++spins) {
-        if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) >= want) return PGW_OK;
-        if ((spins & 0xFFFF) == 0) {
-            hipError_t q = hipStreamQuery(ctx->stream);
-            if (q == hipSuccess) {
-                if (__atomic_load_n(&m->seq, __ATOMIC_ACQUIRE) >= want) return PGW_OK;
-                return fail(ctx, PGW_ERR_HIP, "surface-pressure loop: a pass finished without reporting to the host mailbox");
-            }
-            if (q != hipErrorNotReady) return fail(ctx, PGW_ERR_HIP, "surface-pressure loop: %s", hipGetErrorString(q));
-        }
-        __builtin_ia32_pause();
-    }
-}
-
-static int pair_staged_env() {
-    // tuning knob: 1 = stage the delta source columns in LDS (7 waves/CU at S = 19); default 0 = gather them
-    // from global memory when a column's bracket changes (12 waves/CU; measured 25 % faster: 1.85 vs 2.44 ms)
-    const char *e = getenv("PGW_PAIR_STAGED");
-    return (e && e[0] == '1') ? 1 : 0;
-}
-
-static int pair_vec_env() {
-    const char *e = getenv("PGW_PAIR_VEC");     // tuning knob: 16 B per lane in the delta-pair kernels
-    return (e && e[0] == '1') ? 1 : 0;
-}
-
-static int full_column_env() {
-    const char *e = getenv("PGW_FULL_COLUMN");
-    return (e && e[0] == '1') ? 1 : 0;
-}
 
 extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta_pgw,
                                   const void *hur_pgw, const void *PS, const void *FIS, const double *phi_ref_era,
@@ -836,7 +765,7 @@ extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long 
     rc = status_reset(ctx);
     if (rc) return rc;
     launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref,
-                p_ref_field, adj_factor, full_column_env(), apply_adj ? 1 : 0);
+                p_ref_field, adj_factor, ctx->opt[PGW_OPT_FULL_COLUMN], apply_adj ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     rc = status_check(ctx);
     if (max_abs_err) *max_abs_err = max_err_of(ctx);
@@ -847,6 +776,7 @@ extern "C" int pgw_update_ps(pgw_ctx *ctx, int dtype, long long n, const void *P
                              const double *adj_ps, void *ps_pgw) {
     NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
     NEED(ctx, n >= 1 && PS && delta_ps && adj_ps && ps_pgw, "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     DISPATCH_T(dtype, hipLaunchKernelGGL((k_update_ps<T>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, n,
                                          (const T *)PS, delta_ps, adj_ps, (T *)ps_pgw));
     HIPCHK(ctx, hipGetLastError());
@@ -861,14 +791,16 @@ extern "C" int pgw_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long 
     NEED(ctx, T && QV && PS && FIS && phi_ref, "null pointer");
     int rc = status_reset(ctx);
     if (rc) return rc;
-    launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_ref, full_column_env(), p_ref_field);
+    launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_ref, ctx->opt[PGW_OPT_FULL_COLUMN], p_ref_field);
     HIPCHK(ctx, hipGetLastError());
     return status_check(ctx);
 }
 
 // The loop of step_03_apply_to_era.py:182-319 given the iterate-independent vapour pressure
 // `evap` = hur_pgw/100 * e_sat(ta_pgw) (functions.py:123).  Shared by pgw_adjust_ps_loop and
-// pgw_step03_file.
+// pgw_step03_file.  The host reads max|err| after every pass (status copy + stream synchronisation) before it
+// launches the next - the reference's control flow literally (four device-assisted variants, with the passes
+// enqueued ahead of the host, all measured slower: DESIGN.md section 4, "tried and dropped").
 // local_nplev > 0 selects p_ref_inp = None (step_03:219-253): dzg_b/dzg_a are then the full
 // (ntime, nplev, ncol) zg records and `plev_file` the plev coordinate in file order.
 static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *PS, const void *FIS,
@@ -876,7 +808,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                        const void *dzg_b, const void *dzg_a, double x_hi, double x_new, double p_ref,
                        double adj_factor, double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
                        double *max_err_hist, int hist_len, int local_nplev = 0, const double *plev_file = nullptr,
-                       const double *akbk_N = nullptr, bool status_armed = false, int qv_done_levels = 0) {
+                       bool status_armed = false, int qv_done_levels = 0) {
     const long long n2 = (long long)ntime * ncol;
     void *state = nullptr;
     int rc;
@@ -884,149 +816,29 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
     double *pref_f = adj_ps + n2;
     int *pref_idx = (int *)(pref_f + n2);
-    const int full_column = full_column_env();
+    const int full_column = ctx->opt[PGW_OPT_FULL_COLUMN];
     const bool local = local_nplev > 0;
     PlevTable ptf;
     memset(&ptf, 0, sizeof(ptf));
     if (local) {
         ptf.n = local_nplev;
         for (int i = 0; i < local_nplev; ++i) ptf.p[i] = plev_file[i];
+        HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
     } else {
         // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it).
-        // With the device-controlled loop nothing is read back until the end: kernel-reported errors stay in
-        // the status block (first code wins, smallest column) and are raised by the final status_check.
         if (!status_armed && (rc = status_reset(ctx))) return rc;
         launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column);
         HIPCHK(ctx, hipGetLastError());
         // status_armed (pgw_step03_file with the model-top check off): nothing is read back before the first pass;
         // the status block keeps the first error any kernel reported, in stream order, so the first pass's check
         // raises what an immediate check would have raised
-        if (!device_loop_env() && !status_armed && (rc = status_check(ctx))) return rc;
+        if (!status_armed && (rc = status_check(ctx))) return rc;
         // g * (time-interpolated zg delta at p_ref)   step_03:292-295
         DISPATCH_T(dtype, {
             DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
             hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi,
                                delta_ps, adj_ps);                                       // + delta_ps = adj_ps = 0  :182-184
         });
-    }
-    if (local) HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
-
-    if (!local && device_loop_env() >= 2) {
-        // Modes 2-4 (see device_loop_env): every pass first checks the device-side `done` flag (set by the last
-        // block of the pass that reached max|err| <= thresh) and returns at once if it is set, so a pass speculated
-        // beyond convergence changes nothing.  The host applies the reference's control flow (step_03:189, 313-319)
-        // to what it reads from the read-back ring (mode 2) or the polled mailbox (modes 3, 4).
-        const int mode = device_loop_env();
-        const bool mailbox = mode >= 3, speculate = mode <= 3;
-        NEED(ctx, max_n_iter <= 32, "max_n_iter must be <= 32 for the device-assisted loop");
-        void *lsv = nullptr;
-        if ((rc = ws_get(ctx, 4, sizeof(LoopState), &lsv))) return rc;
-        LoopState *ls = (LoopState *)lsv;
-        LoopState init;
-        memset(&init, 0, sizeof(init));
-        if (mailbox) {
-            if (!ctx->mail)                                                 // opt-in modes only: allocated on first use
-                HIPCHK(ctx, hipHostMalloc(&ctx->mail, sizeof(LoopMail), hipHostMallocMapped | hipHostMallocCoherent));
-            void *dmail = nullptr;
-            HIPCHK(ctx, hipHostGetDevicePointer(&dmail, ctx->mail, 0));
-            init.mail = (unsigned long long)(uintptr_t)dmail;
-            ctx->mail->done = 0;
-            __atomic_store_n(&ctx->mail->seq, 0u, __ATOMIC_RELEASE);
-        }
-        HIPCHK(ctx, hipMemcpyAsync(ls, &init, sizeof(LoopState), hipMemcpyHostToDevice, ctx->stream));   // pageable: staged before return
-        auto enqueue_pass = [&](int slot) -> int {
-            launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
-                        adj_factor, full_column, 1, ls, thresh);
-            if (!mailbox) {
-                HIPCHK(ctx, hipMemcpyAsync(&ctx->h_loop[slot], ls, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(ctx, hipEventRecord(ctx->loop_ev[slot], ctx->stream));
-            }
-            return PGW_OK;
-        };
-        if ((rc = enqueue_pass(0))) return rc;
-        unsigned long long touched = 0;
-        int passes = 0;
-        bool too_many = false;
-        for (int k = 0;; ++k) {
-            if (speculate && (rc = enqueue_pass((k + 1) % 3))) return rc;   // the next pass, before pass k is known
-            int done;
-            double err_k;
-            unsigned long long lev_k;
-            if (mailbox) {
-                if ((rc = poll_mail(ctx, (unsigned int)(k + 1)))) return rc;
-                done = ctx->mail->done; err_k = ctx->mail->max_err[k & 31]; lev_k = ctx->mail->levels[k & 31];
-            } else {
-                HIPCHK(ctx, hipEventSynchronize(ctx->loop_ev[k % 3]));
-                const LoopState &h = ctx->h_loop[k % 3];                    // state after pass k
-                done = h.done; err_k = h.max_err[k & 31]; lev_k = h.levels[k & 31];
-            }
-            passes = k + 1;
-            if (k < 32) {
-                touched += lev_k;
-                if (max_err_hist && k < hist_len) max_err_hist[k] = err_k;
-            }
-            if (k + 2 > max_n_iter) { too_many = true; break; }            // it += 1 ; if it > max_n_iter: raise   :313-319
-            if (done) break;                                                // while phi_ref_max_error > thresh      :189
-            if (!speculate && (rc = enqueue_pass(0))) return rc;
-        }
-        ctx->last_levels_touched = touched;
-        if (n_iter) *n_iter = passes;
-        if (!too_many && (ps_pgw || hus_pgw)) {
-            int vec = pick_vec(dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
-            Levels lv = levels_of(ctx);
-            Prof pr(ctx, PGW_K_FINALIZE);
-            DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
-                                                        ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
-                                                        (T *)ps_pgw, (T *)hus_pgw, qv_done_levels));
-        }
-        HIPCHK(ctx, hipGetLastError());
-        if ((rc = status_check(ctx))) return rc;                            // kernel-reported data errors first
-        if (too_many) {
-            ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
-            ctx->err_col = -1;
-            return PGW_ERR_NOT_CONVERGED;
-        }
-        return PGW_OK;
-    }
-
-    if (!local && device_loop_env() == 1) {
-        // All passes are enqueued back to back; each one checks the device-side `done` flag and the block
-        // that finishes a pass last publishes max|err| (k_adjust_ps_step).  The reference raises when the pass
-        // counter exceeds max_n_iter even if that pass converged (step_03:313-319), i.e. max_n_iter passes can
-        // run and at most max_n_iter - 1 may be needed.
-        NEED(ctx, max_n_iter <= 32, "max_n_iter must be <= 32 for the device-controlled loop");
-        void *lsv = nullptr;
-        if ((rc = ws_get(ctx, 4, sizeof(LoopState), &lsv))) return rc;
-        LoopState *ls = (LoopState *)lsv;
-        HIPCHK(ctx, hipMemsetAsync(ls, 0, sizeof(LoopState), ctx->stream));
-        for (int k = 0; k < max_n_iter; ++k)
-            launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
-                        adj_factor, full_column, 1, ls, thresh);
-        if (ps_pgw || hus_pgw) {
-            int vec = pick_vec(dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
-            Levels lv = levels_of(ctx);
-            Prof pr(ctx, PGW_K_FINALIZE);
-            DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
-                                                        ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
-                                                        (T *)ps_pgw, (T *)hus_pgw, qv_done_levels));
-        }
-        HIPCHK(ctx, hipGetLastError());
-        LoopState h;
-        HIPCHK(ctx, hipMemcpyAsync(&h, ls, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
-        if ((rc = status_check(ctx))) return rc;                           // synchronises the stream
-        if (n_iter) *n_iter = h.n_iter;
-        unsigned long long touched = 0;
-        for (int k = 0; k < h.n_iter && k < 32; ++k) {
-            touched += h.levels[k];
-            if (max_err_hist && k < hist_len) max_err_hist[k] = h.max_err[k];
-        }
-        ctx->last_levels_touched = touched;
-        if (h.n_iter >= max_n_iter) {                                      // :315-319
-            ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
-            ctx->err_col = -1;
-            return PGW_ERR_NOT_CONVERGED;
-        }
-        return PGW_OK;
     }
 
     double phi_ref_max_error = INFINITY;                                   // :186
@@ -1044,8 +856,8 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             // delta_ps += adj_ps ; per-column p_ref (never lower than last pass) ; g*zg at that level
             DISPATCH_T(dtype, {
                 DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
-                hipLaunchKernelGGL((k_local_p_ref<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, ptf, akbk_N[0],
-                                   akbk_N[1], n2, (const T *)PS, delta_ps, adj_ps, z, ncol, it == 1 ? 1 : 0, pref_f,
+                hipLaunchKernelGGL((k_local_p_ref<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, ptf, ctx->h_akN,
+                                   ctx->h_bkN, n2, (const T *)PS, delta_ps, adj_ps, z, ncol, it == 1 ? 1 : 0, pref_f,
                                    pref_idx, dphi, ctx->d_status);
             });
             launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, 0.0, phi_era, full_column, pref_f);   // :280-287
@@ -1053,7 +865,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                         adj_factor, full_column, 0);
         } else {
             launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
-                        adj_factor, full_column, 1, nullptr, 0.0, cur, blk[it & 1]);
+                        adj_factor, full_column, 1, cur, blk[it & 1]);
         }
         HIPCHK(ctx, hipGetLastError());
         if ((rc = status_check(ctx, cur))) return rc;
@@ -1071,7 +883,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     ctx->last_levels_touched = touched;
     if (n_iter) *n_iter = it - 1;
     if (ps_pgw || hus_pgw) {
-        int vec = pick_vec(dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
+        int vec = pick_vec(ctx, dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
         Levels lv = levels_of(ctx);
         Prof pr(ctx, PGW_K_FINALIZE);
         DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
@@ -1158,44 +970,17 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     }
 
     // ---- ta + hur -> T_pgw, e_pgw   and   ua + va -> U_pgw, V_pgw
-    // One column per thread: the pair kernels are bound by fp64 VALU work and LDS capacity
-    // (2*S*8 B of staged source values per column), not by load width.
+    // One column per thread: these kernels are bound by fp64 VALU work and register footprint, not by load width.
     {
         const int S = a->nplev;
-        const bool staged = pair_staged_env();
-        const size_t per_col = staged ? (size_t)2 * S * sizeof(double) : 0;
-        const size_t tab = (size_t)2 * N * sizeof(double);            // akm | bkm
-        // STAGED: LDS capacity bounds the occupancy (304 B of source values per column at S = 19):
-        // one-wave blocks pack the 160 KiB best (7 waves per CU at S = 19, N = 137)
-        const int tpb = staged ? ((per_col * 128 + tab <= 20 * 1024) ? 128 : 64) : 128;
-        const size_t lds = per_col * tpb + tab;
-        if (lds > 150 * 1024) return fail(ctx, PGW_ERR_ARG, "pgw_step03_file: too many delta levels (%d)", S);
-        const unsigned int grid = nblocks((long long)ntime * ncol, tpb);
         // one host synchronisation per file: without the model-top check nothing has to be read back
-        // between the kernels (errors stay in the status block until the loop's final check)
-        const bool defer = !check_top && !a->local_p_ref;    // kernel-reported errors are read with the first loop pass
-#define LAUNCH_PAIR(THERMO, TPB, FA, FB, D3, DS, PH, OA, OB, OH, STREAM)                                                      \
-    do {                                                                                                               \
-        if (lds > 64 * 1024)                                                                                           \
-            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), TPB, true>,               \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-        if (staged)                                                                                                    \
-        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), TPB, true>), dim3(grid), dim3(TPB), lds, STREAM,   \
-                           ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
-                           ctx->d_status);                                                                             \
-        else                                                                                                           \
-        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), TPB, false>), dim3(grid), dim3(TPB), lds, STREAM,  \
-                           ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
-                           ctx->d_status);                                                                             \
-    } while (0)
-        // both storage types: with fp32 storage the quad kernel was slower than the two pair kernels at first (2.62 vs
-        // 2.49 ms); after the instruction trims it is faster there too (2.28 vs 2.38 ms, and the finalize kernel skips
-        // the pure-pressure levels: 0.14 vs 0.21 ms)
-        if (quad_env() && !(!check_top && side_stream_env())) {
-            // ---- all four variables in one kernel
+        // between the kernels (errors stay in the status block until the loop's first check)
+        const bool defer = !check_top && !a->local_p_ref;
+        if ((rc = status_reset(ctx))) return rc;
+        if (ctx->opt[PGW_OPT_QUAD]) {
+            // ---- all four variables in one kernel (production)
             const size_t qlds = (size_t)3 * N * sizeof(double);
-            qv_done = full_column_env() ? 0 : ctx->n_pure;     // full-column passes read e at every level
-            if ((rc = status_reset(ctx))) return rc;
+            qv_done = ctx->opt[PGW_OPT_FULL_COLUMN] ? 0 : ctx->n_pure;     // full-column passes read e at every level
             {
                 Prof pr(ctx, PGW_K_QUAD_DELTA);
 #define LAUNCH_QUAD(OT, LERP_)                                                                                        \
@@ -1221,82 +1006,55 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
 #undef LAUNCH_QUAD
             }
             HIPCHK(ctx, hipGetLastError());
-            if (!defer) {
-                if ((rc = status_check(ctx))) return rc;
-                if ((rc = top_check())) return rc;
-            }
         } else {
-        if ((rc = status_reset(ctx))) return rc;
-        HIPCHK(ctx, hipEventRecord(ctx->fork_ev, ctx->stream));      // everything enqueued before this file's kernels
-        {
-            Prof pr(ctx, PGW_K_THERMO_DELTA);
-            DISPATCH_T(dtype, {
-                PairSrc<T> d3{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
-                              {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
-                PairSrc<T> ds{{(const T *)a->tas_b, exact ? nullptr : (const T *)a->tas_a, a->x_hi, a->x_new},
-                              {(const T *)a->hurs_b, exact ? nullptr : (const T *)a->hurs_a, a->x_hi, a->x_new}};
-                DeltaSrc<T> ph{(const T *)a->pshist_b, exact ? nullptr : (const T *)a->pshist_a, a->x_hi, a->x_new};
-                if (tpb == 128) LAUNCH_PAIR(true, 128, (const T *)a->T, (const T *)a->QV, d3, ds, ph, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, ctx->stream);
-                else LAUNCH_PAIR(true, 64, (const T *)a->T, (const T *)a->QV, d3, ds, ph, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, ctx->stream);
-            });
+            // ---- PGW_OPT_QUAD = 0: the two pair kernels the quad kernel replaced (kept as an independently written
+            // cross-check of the same arithmetic: tests/test_hip_parity.py::test_kernel_variants_are_bit_identical)
+            const size_t lds = (size_t)2 * N * sizeof(double);            // akm | bkm
+            const unsigned int grid = nblocks((long long)ntime * ncol, 128);
+#define LAUNCH_PAIR(THERMO, FA, FB, D3, DS, PH, OA, OB, OH)                                                                   \
+        hipLaunchKernelGGL((k_delta_pair<T, 1, THERMO, (THERMO ? 2 : PAIR_U), 128>), dim3(grid), dim3(128), lds, ctx->stream,  \
+                           ctx->plev_tab, lv, ntime, ncol, FA, FB, (const T *)a->PS, D3, DS, PH, check_top, OA, OB, OH, \
+                           ctx->d_status)
+            {
+                Prof pr(ctx, PGW_K_THERMO_DELTA);
+                DISPATCH_T(dtype, {
+                    PairSrc<T> d3{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
+                                  {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
+                    PairSrc<T> ds{{(const T *)a->tas_b, exact ? nullptr : (const T *)a->tas_a, a->x_hi, a->x_new},
+                                  {(const T *)a->hurs_b, exact ? nullptr : (const T *)a->hurs_a, a->x_hi, a->x_new}};
+                    DeltaSrc<T> ph{(const T *)a->pshist_b, exact ? nullptr : (const T *)a->pshist_a, a->x_hi, a->x_new};
+                    LAUNCH_PAIR(true, (const T *)a->T, (const T *)a->QV, d3, ds, ph, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out);
+                });
+            }
+            {
+                Prof pr(ctx, PGW_K_WIND_DELTA);
+                DISPATCH_T(dtype, {
+                    PairSrc<T> d3{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
+                                  {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
+                    PairSrc<T> ds{{nullptr, nullptr, 0.0, 0.0}, {nullptr, nullptr, 0.0, 0.0}};
+                    DeltaSrc<T> ph{nullptr, nullptr, 0.0, 0.0};
+                    LAUNCH_PAIR(false, (const T *)a->U, (const T *)a->V, d3, ds, ph, (T *)a->U_out, (T *)a->V_out, (T *)nullptr);
+                });
+            }
+#undef LAUNCH_PAIR
+            HIPCHK(ctx, hipGetLastError());
         }
-        HIPCHK(ctx, hipGetLastError());
         if (!defer) {
             if ((rc = status_check(ctx))) return rc;
             if ((rc = top_check())) return rc;
-            if ((rc = status_reset(ctx))) return rc;
         }
-        // The wind pair touches neither the status block (no surface insertion, no model-top check when it is
-        // ignored) nor anything the loop reads, so it runs on the side stream beside the ta+hur pair and the loop:
-        // the HBM-bound kernel fills the memory pipe while the fp64-VALU-bound one computes.  pgw_step03_file joins
-        // the side stream before it returns.
-        const bool side = !check_top && side_stream_env();
-        hipStream_t wstream = side ? ctx->stream2 : ctx->stream;
-        if (side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->fork_ev, 0));
-        {
-            Prof pr(ctx, PGW_K_WIND_DELTA, wstream);
-            DISPATCH_T(dtype, {
-                PairSrc<T> d3{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
-                              {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
-                PairSrc<T> ds{{nullptr, nullptr, 0.0, 0.0}, {nullptr, nullptr, 0.0, 0.0}};
-                DeltaSrc<T> ph{nullptr, nullptr, 0.0, 0.0};
-                if (tpb == 128) LAUNCH_PAIR(false, 128, (const T *)a->U, (const T *)a->V, d3, ds, ph, (T *)a->U_out, (T *)a->V_out, (T *)nullptr, wstream);
-                else LAUNCH_PAIR(false, 64, (const T *)a->U, (const T *)a->V, d3, ds, ph, (T *)a->U_out, (T *)a->V_out, (T *)nullptr, wstream);
-            });
-        }
-        if (side) HIPCHK(ctx, hipEventRecord(ctx->join_ev, ctx->stream2));
-        HIPCHK(ctx, hipGetLastError());
-        if (check_top) {
-            if ((rc = status_check(ctx))) return rc;
-            if ((rc = top_check())) return rc;
-        }
-        }   // pair kernels
-#undef LAUNCH_PAIR
     }
 
     // ---- fixed-point loop + final PS, QV
     a->n_iter = 0;
     for (int i = 0; i < 32; ++i) a->max_err_hist[i] = NAN;
-    double akbk_N[2] = {0.0, 0.0};
-    if (a->local_p_ref) {
-        NEED(ctx, a->zg3_b != nullptr, "local_p_ref needs the full zg records (zg3_b / zg3_a)");
-        std::vector<double> h(2);
-        HIPCHK(ctx, hipMemcpyAsync(&akbk_N[0], ctx->d_levels + N, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(&akbk_N[1], ctx->d_levels + (N + 1) + N, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    if (a->local_p_ref) NEED(ctx, a->zg3_b != nullptr, "local_p_ref needs the full zg records (zg3_b / zg3_a)");
     rc = run_ps_loop(ctx, dtype, ntime, ncol, a->PS, a->FIS, a->T, a->QV, a->T_out, evap,
                      a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a, a->x_hi,
                      a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
-                     a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev, akbk_N,
+                     a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev,
                      !check_top && !a->local_p_ref, qv_done);
     a->levels_touched = ctx->last_levels_touched;
-    if (!check_top && side_stream_env()) {
-        // join: later work on the main stream (and the caller after the next synchronisation) sees U_out, V_out
-        hipError_t e1 = hipStreamWaitEvent(ctx->stream, ctx->join_ev, 0);
-        hipError_t e2 = hipStreamSynchronize(ctx->stream2);
-        if (rc == PGW_OK && (e1 != hipSuccess || e2 != hipSuccess)) return fail(ctx, PGW_ERR_HIP, "side stream join failed");
-    }
     return rc;
 }
 

@@ -27,30 +27,6 @@ struct DevStatus {
     unsigned long long levels_touched; // sum over columns of levels read (early-exit kernels)
 };
 
-// Device-resident control block of the surface-pressure loop (step_03:182-319) when the passes are
-// enqueued back to back without a host round trip: every pass kernel returns at once if `done`
-// is set; the block that arrives last publishes the pass's max|err|, decides `done` with the
-// reference's test (NOT err > thresh, so NaN stops the loop too) and re-arms the accumulators.
-struct LoopState {
-    int done;                          // 1 once a pass ended with max|err| <= thresh
-    int n_iter;                        // passes executed
-    unsigned int arrivals;             // blocks of the current pass that have reported
-    int pad;
-    double max_err[32];
-    unsigned long long levels[32];     // levels read per pass (bytes-moved accounting)
-    unsigned long long mail;           // address of a LoopMail in coherent host memory, or 0
-};
-
-// Host-visible mailbox of the loop (pinned, coherent host memory mapped into the device): the block that finishes a
-// pass last stores the pass result here and then publishes `seq` = passes finished with a system-scope release
-// store; the host polls `seq` instead of paying a copy + stream synchronisation per pass.
-struct LoopMail {
-    unsigned int seq;
-    int done;
-    double max_err[32];
-    unsigned long long levels[32];
-};
-
 template <typename T, int V> struct alignas(sizeof(T) * V) Pack { T v[V]; };
 
 template <typename T, int V>

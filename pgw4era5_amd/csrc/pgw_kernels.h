@@ -340,15 +340,11 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
                                                           double *__restrict__ delta_ps, double *__restrict__ adj_ps,
                                                           double p_ref_s, const double *__restrict__ p_ref_f,
                                                           double adj_factor, int full_column, int apply_adj,
-                                                          DevStatus *st, LoopState *ls, double thresh,
-                                                          DevStatus *clear) {
+                                                          DevStatus *st, DevStatus *clear) {
     __shared__ double s_max[BLOCK / 64];
     __shared__ unsigned int s_valid[BLOCK / 64];
     __shared__ double s_lev[LEVTAB_DOUBLES];
-    // device-controlled loop: a pass enqueued after convergence is a no-op (the flag was written by
-    // an earlier kernel on this stream, so the kernel boundary makes it visible)
-    if (ls && ls->done) return;
-    if (clear && blockIdx.x == 0 && threadIdx.x == 0) {       // status block of the NEXT pass (host-controlled loop)
+    if (clear && blockIdx.x == 0 && threadIdx.x == 0) {       // status block of the NEXT pass
         DevStatus z;
         z.code = 0; z.nan_seen = 0; z.col = ~0ull; z.max_bits = 0; z.valid = 0;
         z.min_targ_bits = ~0ull; z.min_src_bits = ~0ull; z.levels_touched = 0;
@@ -403,42 +399,11 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
         unsigned long long tch = s_valid[0];
 #pragma unroll
         for (int i = 1; i < BLOCK / 64; ++i) { m = fmax(m, s_max[i]); tch += s_valid[i]; }
-        unsigned long long r0 = 0, r1 = 0, r2;
         if (m >= 0.0) {
-            r0 = atomicMax(&st->max_bits, dbits(m));
-            r1 = atomicAdd(&st->valid, 1ull);
+            atomicMax(&st->max_bits, dbits(m));
+            atomicAdd(&st->valid, 1ull);
         }
-        r2 = atomicAdd(&st->levels_touched, tch);
-        if (ls) {
-            // Last-arriver protocol without fences: the three agent-scope atomics above are the RETURNING forms and
-            // their results are consumed here, so the wave has seen them performed at the coherence point before it
-            // draws its arrival ticket (a __threadfence per block would write back the XCD's L2 4 056 times per
-            // launch: measured +20 % on the pass).  The block that draws the last ticket reads the accumulators with
-            // atomic RMWs; its plain stores are consumed by the next kernel / copy on the stream (kernel boundary).
-            asm volatile("" ::"v"(r0), "v"(r1), "v"(r2));
-            unsigned int ticket = atomicAdd(&ls->arrivals, 1u);
-            if (ticket == gridDim.x - 1) {
-                unsigned long long bits = atomicMax(&st->max_bits, 0ull);
-                unsigned long long nvalid = atomicAdd(&st->valid, 0ull);
-                unsigned long long lev = atomicAdd(&st->levels_touched, 0ull);
-                double mx = nvalid ? __longlong_as_double((long long)bits) : __builtin_nan("");   // xarray .max() of all-NaN
-                int it = ls->n_iter;
-                if (it < 32) { ls->max_err[it] = mx; ls->levels[it] = lev; }
-                ls->n_iter = it + 1;
-                if (!(mx > thresh)) ls->done = 1;                         // step_03:189
-                atomicExch(&st->max_bits, 0ull);                          // re-arm for the next pass
-                atomicExch(&st->valid, 0ull);
-                atomicExch(&st->levels_touched, 0ull);
-                atomicExch(&ls->arrivals, 0u);
-                LoopMail *mail = (LoopMail *)ls->mail;
-                if (mail) {                                               // tell the polling host
-                    if (it < 32) { mail->max_err[it] = mx; mail->levels[it] = lev; }
-                    mail->done = !(mx > thresh) ? 1 : 0;
-                    __threadfence_system();
-                    __hip_atomic_store(&mail->seq, (unsigned int)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-        }
+        atomicAdd(&st->levels_touched, tch);
     }
 }
 
@@ -509,102 +474,15 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
 
 // =====================================================================================
 // a6  interp_logp_4d, signature-faithful                       functions.py:434-580
-// Source columns (ln p and values) are staged once in LDS, laid out [level][thread] so a
-// wave's read of one level is conflict-free; each target level is then located by the
-// reference's "first s with src[s] == x or src[s] > x" rule.  The scan resumes from the
-// previous hit while targets ascend (all earlier sources are < the previous target <= x,
-// so they cannot match) and restarts from 0 otherwise -> identical selection, O(N+S).
+// Each target level is located by the reference's "first s with src[s] == x or src[s] > x" rule.  The scan
+// resumes from the previous hit while targets ascend (all earlier sources are < the previous target <= x, so
+// they cannot match) and restarts from 0 otherwise -> identical selection, O(N+S).
 // =====================================================================================
-template <int MODE>
-__device__ __forceinline__ double interp_pick(int s, int S, double x, const double *sx, const double *sy,
-                                              int stride, bool &extrap) {
-    // s = first index with sx[s] >= x (NaN-safe), S if none
-    int i1, i2;
-    extrap = false;
-    if (s >= S) {                                  // above range            :554-561
-        extrap = true;
-        if (MODE == 1) { i1 = S - 2; i2 = S - 1; } else { i1 = i2 = S - 1; }
-    } else {
-        double xs = sx[s * stride];
-        if (xs == x) { i1 = i2 = s; }              // exact                  :540-543
-        else if (s == 0) {                         // below range            :530-538
-            extrap = true;
-            if (MODE == 1) { i1 = 0; i2 = 1; } else { i1 = i2 = 0; }
-        } else { i1 = s - 1; i2 = s; }             // bracket                :545-548
-    }
-    if (extrap && MODE == 3) return __builtin_nan("");          // :569-570
-    if (i1 == i2) return sy[i1 * stride];                       // :572-573
-    double x1 = sx[i1 * stride], x2 = sx[i2 * stride];
-    double y1 = sy[i1 * stride], y2 = sy[i2 * stride];
-    return y1 + (x - x1) * (y2 - y1) / (x2 - x1);               // :575-578
-}
-
-template <typename T, int MODE, int TPB>
-__global__ __launch_bounds__(TPB) void k_interp_logp(int ntime, int S, int N, long long ncol,
-                                                     const T *__restrict__ var, const T *__restrict__ srcP,
-                                                     const T *__restrict__ trgP, T *__restrict__ out,
-                                                     int logp_in, DevStatus *st) {
-    extern __shared__ double lds[];                 // sx[S][TPB], sy[S][TPB]
-    double *sx = lds + threadIdx.x;
-    double *sy = lds + (size_t)S * TPB + threadIdx.x;
-    long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
-    if (flat >= (long long)ntime * ncol) return;    // no barrier in this kernel: columns are private
-    long long t = flat / ncol, c = flat - t * ncol;
-    const T *pv = var + t * S * ncol + c;
-    const T *pp = srcP + t * S * ncol + c;
-    for (int s = 0; s < S; ++s) {
-        sx[s * TPB] = logp_in ? (double)pp[(long long)s * ncol] : pgw_log((double)pp[(long long)s * ncol]);   // :470
-        sy[s * TPB] = (double)pv[(long long)s * ncol];
-    }
-    if (sx[(S - 1) * TPB] < sx[0]) { report(st, 10, flat); }     // :500-501
-    const T *pt = trgP + t * N * ncol + c;
-    T *po = out + t * N * ncol + c;
-    double x_first = (double)pt[0], x_last = (double)pt[(long long)(N - 1) * ncol];
-    if (!logp_in) { x_first = pgw_log(x_first); x_last = pgw_log(x_last); }
-    if (x_last < x_first) { report(st, 11, flat); }              // :502-503
-    int j = 0;
-    double xprev = -__builtin_inf();
-    // chunks of 4 target levels: the next chunk's loads are in flight while this one is interpolated
-    constexpr int U = 4;
-    double nx[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)(u < N ? u : N - 1) * ncol];
-    for (int l0 = 0; l0 < N; l0 += U) {
-        double cx[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cx[u] = nx[u];
-        if (l0 + U < N) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int l = l0 + u;
-            if (l < N) {
-                double x = cx[u];
-                if (!logp_in) x = pgw_log(x);                            // :471
-                if (!(x >= xprev)) j = 0;                                // restart (descending or NaN)
-                while (j < S) {
-                    double xs = sx[j * TPB];
-                    if (xs == x || xs > x) break;
-                    ++j;
-                }
-                bool extrap;
-                double y = interp_pick<MODE>(j, S, x, sx, sy, TPB, extrap);
-                if (MODE == 0 && extrap) report(st, 12, flat);           // :564-566
-                po[(long long)l * ncol] = (T)y;
-                xprev = (x == x) ? x : __builtin_inf();                  // after a NaN target restart
-            }
-        }
-    }
-}
-
-// Streaming variant (default): nothing is staged.  A column keeps a window of its source profile in registers -
-// levels j-2, j-1, j (the scan position) and j+1, with the loads of level j+2 in flight - and moves it forward when
-// a target passes level j, so every source element is read exactly once, one scan step ahead of its use, and the
-// kernel runs at full occupancy instead of the 8 waves per CU the [level][thread] LDS tile allows at S = 19.
-// Selection rule, restart on a non-ascending / NaN target (re-reads the column from level 0; rare) and error
-// reporting are those of k_interp_logp.
+// Nothing is staged.  A column keeps a window of its source profile in registers - levels j-2, j-1, j (the scan
+// position) and j+1, with the loads of level j+2 in flight - and moves it forward when a target passes level j, so
+// every source element is read exactly once, one scan step ahead of its use, and the kernel runs at full occupancy
+// (a [level][thread] LDS tile of the source columns caps the CU at 8 waves at S = 19: 0.91 vs 0.54 ms).
+// A non-ascending / NaN target restarts the scan (re-reads the column from level 0; rare).
 #ifndef PGW_INTERP_MINB
 #define PGW_INTERP_MINB 1
 #endif
@@ -894,37 +772,30 @@ struct PairSrc {       // the two variables of a pair
     DeltaSrc<T> a, b;
 };
 
-// The S source values of both variables of every column (time-lerped, surface delta inserted)
-// are staged ONCE in LDS, laid out [level][thread] (conflict-free for any per-lane level index),
-// so the level loop does no global gathers: a gather's `s_waitcnt vmcnt(0)` would also wait for
-// the prefetched rows and all earlier stores and serialise the whole pipeline.
+// Source values are gathered from global memory when a column's bracket changes and cached in registers
+// (staging the S source values of every column in LDS, 304 B per column at S = 19, capped the CU at 7 waves and
+// measured 25 % slower: 2.44 vs 1.85 ms).
 // THERMO: 4 waves/SIMD (VGPR <= 128) with 2-level chunks measured 6 % faster than 3 waves with 4-level
 // chunks (fp64-VALU/latency bound); the wind pair is HBM bound and prefers the deeper prefetch.
-template <typename T, int V, bool THERMO, int U, int TPB, bool STAGED>
-__global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
+template <typename T, int V, bool THERMO, int U, int TPB>
+__global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                     const T *__restrict__ fa, const T *__restrict__ fb,
                                                     const T *__restrict__ PS,
                                                     PairSrc<T> d3, PairSrc<T> dsfc, DeltaSrc<T> psh,
                                                     int check_top, T *__restrict__ out_a, T *__restrict__ out_b,
                                                     T *__restrict__ out_hur, DevStatus *st) {
-    // STAGED:  ya[S][V*TPB] | yb[S][V*TPB] | akm[N] | bkm[N]   (source values in LDS)
-    // !STAGED: akm[N] | bkm[N]; source values are gathered from global memory when a column's
-    //          bracket changes and cached in registers (more waves per CU, a vmcnt(0) stall per change)
-    extern __shared__ double lds_pair[];
+    extern __shared__ double lds_pair[];            // akm[N] | bkm[N]
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
     __shared__ double s_lnp[MAX_PLEV];
     const int S = pt.n;
-    constexpr int W = V * TPB;                      // column slots per block
-    double *s_akm = lds_pair + (STAGED ? (size_t)2 * S * W : 0), *s_bkm = s_akm + lv.nlev;
+    double *s_akm = lds_pair, *s_bkm = s_akm + lv.nlev;
     for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
     for (int i = threadIdx.x; i < lv.nlev; i += TPB) {
         s_akm[i] = lv.akm[i];
         s_bkm[i] = lv.bkm[i];
     }
     __syncthreads();
-    double *ya = lds_pair + threadIdx.x;            // slot of column v: + v*TPB ; level i: + i*W
-    double *yb = lds_pair + (size_t)S * W + threadIdx.x;
     long long g = (long long)blockIdx.x * TPB + threadIdx.x;
     long long ngroups = (long long)ntime * ncol / V;
     double min_t = __builtin_inf(), min_s = __builtin_inf();
@@ -940,7 +811,7 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
         ColScan sc[V];
         bool fillv[V];
         double sfav[V], sfbv[V];
-        int ci[V];                                    // !STAGED: cached bracket (levels ci, ci+1)
+        int ci[V];                                    // cached bracket (levels ci, ci+1)
         double ca_lo[V], ca_hi[V], cb_lo[V], cb_hi[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -964,21 +835,14 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
                 sc[v].lnps = pgw_log(pshv);
             }
             fillv[v] = fill; sfav[v] = sfa; sfbv[v] = sfb;
-            // stage the source column of both variables (ascending order i <-> file index S-1-i)
-            for (int i = 0; i < S; ++i) {
-                if (STAGED) {
-                    long long o = dbase + v + (long long)(S - 1 - i) * ncol;
-                    bool sfc = THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (fill && i > sc[v].ksfc));
-                    ya[i * W + v * TPB] = sfc ? sfa : d3.a.get(o);
-                    yb[i * W + v * TPB] = sfc ? sfb : d3.b.get(o);
-                }
-                if (check_top) {                                              // np.min(source_P), :417
+            if (check_top) {                                                  // np.min(source_P), :417
+                for (int i = 0; i < S; ++i) {
                     double p = (THERMO && i == sc[v].ksfc) ? pshv : pt.p[i];
                     if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
                 }
             }
         }
-        // !STAGED: values of source levels (i, i+1) of column v, from the register cache or global memory
+        // values of source levels (i, i+1) of column v, from the register cache or global memory (ascending order i <-> file index S-1-i)
         auto fetch = [&](int v, int i1, int i2, double &a1, double &b1, double &a2, double &b2) {
             auto one = [&](int i, double &a, double &b) {
                 bool sfc = THERMO && sc[v].ksfc >= 0 && (i == sc[v].ksfc || (fillv[v] && i > sc[v].ksfc));
@@ -1050,12 +914,7 @@ __global__ __launch_bounds__(TPB, (THERMO && !STAGED) ? 4 : 1) void k_delta_pair
                             else { i1 = c.j - 1; i2 = c.j; }                          // bracket               :545-548
                         }
                         double a1, b1, a2 = 0.0, b2 = 0.0;
-                        if (STAGED) {
-                            a1 = ya[i1 * W + v * TPB]; b1 = yb[i1 * W + v * TPB];
-                            if (i1 != i2) { a2 = ya[i2 * W + v * TPB]; b2 = yb[i2 * W + v * TPB]; }
-                        } else {
-                            fetch(v, i1, i2, a1, b1, a2, b2);
-                        }
+                        fetch(v, i1, i2, a1, b1, a2, b2);
                         double da = a1, db = b1;
                         if (i1 != i2) {                                               // :575-578
                             double x1 = srcx(v, i1), x2 = srcx(v, i2);

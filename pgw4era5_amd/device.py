@@ -158,6 +158,18 @@ class Context:
     def sync(self):
         self._check(self.lib.pgw_sync(self.handle))
 
+    def set_option(self, name, value):
+        """Per-context option of include/pgw_hip.h `enum pgw_option` ('quad', 'full_column', 'force_vec1', 'multipass');
+        returns the previous value."""
+        old = self.get_option(name)
+        self._check(self.lib.pgw_set_option(self.handle, _lib.OPTIONS[name], int(value)))
+        return old
+
+    def get_option(self, name):
+        v = C.c_int(0)
+        self._check(self.lib.pgw_get_option(self.handle, _lib.OPTIONS[name], C.byref(v)))
+        return v.value
+
     def device_name(self):
         buf = C.create_string_buffer(256)
         self._check(self.lib.pgw_device_name(self.handle, buf, 256))

@@ -184,12 +184,10 @@ def test_interp_logp_4d_vs_oracle(F, mode, S, N):
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12, equal_nan=True)
 
 
-@pytest.mark.parametrize('variant', ['stream', 'lds'])
 @pytest.mark.parametrize('mode', ['linear', 'constant', 'nan'])
-def test_interp_logp_unsorted_targets_and_nans(F, monkeypatch, variant, mode):
+def test_interp_logp_unsorted_targets_and_nans(F, mode):
     """Targets that are not monotone inside a column (legal as long as first <= last: the reference scans the
-    source from the start for every target, functions.py:527-548), NaN targets and NaN source pressures; the
-    streaming kernel (default) and the LDS-staged one (PGW_INTERP_LDS=1) must give the same bits."""
+    source from the start for every target, functions.py:527-548), NaN targets and NaN source pressures."""
     rng = np.random.default_rng(77)
     nt, S, N, nlat, nlon = 1, 11, 29, 4, 37
     ps = np.sort(rng.uniform(100, 1e5, (nt, S, nlat, nlon)), axis=1)
@@ -201,12 +199,8 @@ def test_interp_logp_unsorted_targets_and_nans(F, monkeypatch, variant, mode):
     pt[0, 1:, 3, 5] = ps[0, [0, 3, 10] * 9 + [10], 3, 5]     # exact hits incl. first / last source level
     v = rng.normal(0, 3, ps.shape)
     want = O.interp_logp_4d(v, ps, pt, mode)
-    if variant == 'lds':
-        monkeypatch.setenv('PGW_INTERP_LDS', '1')
     got = F.interp_logp_4d(v, ps, pt, mode)
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12, equal_nan=True)
-    monkeypatch.delenv('PGW_INTERP_LDS', raising=False)
-    np.testing.assert_array_equal(got, F.interp_logp_4d(v, ps, pt, mode))
     # float32 storage, pre-computed logs (interp_1d_for_timelatlon signature)
     buf = np.zeros(pt.shape)
     ok = np.isfinite(ps).all(axis=1) & np.isfinite(pt).all(axis=1)
@@ -563,27 +557,19 @@ def test_reinterp_mode_vs_oracle(dtype):
     assert np.abs(base['T'] - got['T']).max() > 1e-6
 
 
-@pytest.mark.parametrize('mode', ['0', '1', '2', '3', '4'])
-def test_device_controlled_loop_matches_host_controlled(monkeypatch, mode):
-    """The loop-control variants (PGW_DEVICE_LOOP; pgw_capi.hip device_loop_env) - 0: the host reads max|err|
-    through a status copy + synchronisation before every launch (the reference's flow literally); 4: the same
-    flow with the result polled from a coherent host mailbox; 3: mailbox + one pass enqueued ahead with a
-    device-side `done` flag; 2: one pass ahead through a read-back ring; 1: all passes enqueued back to back -
-    give bit-identical results, the same iteration count, error history and non-convergence error as the
-    build's default."""
+def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
+    """it > max_n_iter raises even if that pass converged (step_03:313-319)."""
     from pgw4era5_amd import step_03_apply_to_era as s3
+    import pgw4era5_amd.settings as S
     c = _case(9, 16, 30, seed=41)
     a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
-    monkeypatch.setenv('PGW_DEVICE_LOOP', mode)
-    b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
-    assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
-    for k in ['PS', 'T', 'QV', 'U', 'V']:
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    import pgw4era5_amd.settings as S
-    monkeypatch.setattr(S, 'max_n_iter', 3)
+    monkeypatch.setattr(S, 'max_n_iter', a['n_iter'])
     with pytest.raises(ValueError) as e:
         s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
     assert 'did not converge' in str(e.value)
+    monkeypatch.setattr(S, 'max_n_iter', a['n_iter'] + 1)
+    b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    assert b['n_iter'] == a['n_iter']
 
 
 # ------------------------------------------------------------------ ragged / odd shapes, other level sets
@@ -647,20 +633,24 @@ def test_whole_file_errors_reach_python():
         s3.pgw_for_era5_arrays(era, c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
 
 
-@pytest.mark.parametrize('env', [dict(PGW_QUAD='0'), dict(PGW_QUAD='0', PGW_SIDE_STREAM='1'),
-                                 dict(PGW_QUAD='0', PGW_PAIR_STAGED='1'), dict(PGW_QUAD='0', PGW_PAIR_VEC='1'),
-                                 dict(PGW_FULL_COLUMN='1'), dict(PGW_FORCE_VEC1='1')])
+@pytest.mark.parametrize('opts', [dict(quad=0), dict(full_column=1), dict(force_vec1=1), dict(multipass=0),
+                                  dict(multipass=0, full_column=1), dict(quad=0, multipass=0, force_vec1=1)])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
-def test_kernel_variants_are_bit_identical(monkeypatch, env, dtype):
-    """Every selectable variant of the file path (pair kernels instead of the quad kernel, side stream,
-    LDS-staged source columns, 16 B per lane, full-column passes, chunk size, scalar columns) produces
-    the same bits as the default: they differ in scheduling, not in arithmetic."""
+def test_kernel_variants_are_bit_identical(opts, dtype):
+    """Every selectable variant of the file path (pgw_set_option: pair kernels instead of the quad kernel, full-column
+    passes, scalar columns, one launch per loop pass instead of the column-resident multi-pass kernel) produces the
+    same bits as the default: they differ in scheduling, not in arithmetic."""
     from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
     c = _case(8, 12, 27, seed=81, dtype=dtype)
     a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    old = {k: ctx.set_option(k, v) for k, v in opts.items()}
+    try:
+        b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    finally:
+        for k, v in old.items():
+            ctx.set_option(k, v)
     assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
     for k in ['PS', 'T', 'QV', 'U', 'V', 'RELHUM_pgw']:
         if k == 'QV' and dtype == np.float32:
