@@ -259,6 +259,14 @@ typedef struct pgw_file_args {
     /* shapes */
     int dtype, ntime, nlev, nplev, nsoil, ignore_top, max_n_iter;
     int local_p_ref;      /* != 0: p_ref_inp = None, reference pressure chosen per column and pass (step_03:219-253) */
+    int ref_dtype;        /* != 0 (dtype must be PGW_F32): reference-dtype mode - the float32 roundings numpy's promotion
+                             puts into the reference on float32 ERA5 files are reproduced (phi_hl stored float32 per level,
+                             functions.py:141,149; float32 tav of the ERA state :144; float32 delta_ps / ps_pgw,
+                             step_03:182-193; float32 e_sat chain of RELHUM, functions.py:74-105) and, like the reference's
+                             `era + delta` (step_03:170-173), the 4-D outputs T_out, QV_out, U_out, V_out (and hur_pgw_out)
+                             are FLOAT64 arrays; PS_out and the surface riders stay float32.
+                             0: float64 arithmetic on the stored values, outputs in `dtype`. */
+    int _pad0;
     long long ncol;
     /* ERA5 file (device) + small host tables */
     const void *PS, *FIS, *T, *QV, *U, *V;                  /* (ntime,ncol) / (ntime,nlev,ncol)   */

@@ -95,7 +95,8 @@ SIGNATURES = {
 class FileArgs(C.Structure):
     """`pgw_file_args` of include/pgw_hip.h (whole-file entry pgw_step03_file)."""
     _fields_ = (
-        [(n, C.c_int) for n in ('dtype', 'ntime', 'nlev', 'nplev', 'nsoil', 'ignore_top', 'max_n_iter', 'local_p_ref')] +
+        [(n, C.c_int) for n in ('dtype', 'ntime', 'nlev', 'nplev', 'nsoil', 'ignore_top', 'max_n_iter', 'local_p_ref',
+                                'ref_dtype', '_pad0')] +
         [('ncol', C.c_longlong)] +
         [(n, C.c_void_p) for n in ('PS', 'FIS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE')] +
         [('soil_depth', _dp), ('plev', _dp)] +

@@ -435,6 +435,24 @@ extern "C" int pgw_get_full_level_coeffs(pgw_ctx *ctx, double *akm_out, double *
         }                                                                   \
     } while (0)
 
+// storage type T of the ERA5 fields, TL of the PGW level arrays (ta_pgw, e, QV out), REF = reference-dtype mode
+// (float32 files only: T = float, TL = double)
+#define DISPATCH_TLV(dtype, ref, vec, ...)                                   \
+    do {                                                                     \
+        if (dtype == PGW_F64) {                                              \
+            typedef double T; typedef double TL; constexpr bool REF = false; \
+            if (vec == 2) { constexpr int V = 2; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+        } else if (ref) {                                                    \
+            typedef float T; typedef double TL; constexpr bool REF = true;   \
+            if (vec >= 2) { constexpr int V = 2; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } \
+        } else {                                                             \
+            typedef float T; typedef float TL; constexpr bool REF = false;   \
+            if (vec == 4) { constexpr int V = 4; __VA_ARGS__; }              \
+            else if (vec == 2) { constexpr int V = 2; __VA_ARGS__; }         \
+            else { constexpr int V = 1; __VA_ARGS__; }                       \
+        }                                                                    \
+    } while (0)
+
 #define DISPATCH_T(dtype, ...)                                   \
     do {                                                         \
         if (dtype == PGW_F64) { typedef double T; __VA_ARGS__; } \
@@ -711,29 +729,29 @@ static int launch_step(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                        const void *PS, const void *FIS, const double *phi_ref_era, const double *dphi_clim,
                        double *delta_ps, double *adj_ps, double p_ref, const double *p_ref_field,
                        double adj_factor, int full_column, int apply_adj = 1, DevStatus *st = nullptr,
-                       DevStatus *clear = nullptr) {
+                       DevStatus *clear = nullptr, bool ref = false) {
     if (!st) st = ctx->d_status;
     int vec = pick_vec(ctx, dtype, ncol, {ta, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref_field}, 2);
     // fp64 state arrays are read with V doubles per lane: 16*V/2 B alignment follows from ncol % V == 0
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_ADJUST_PS_STEP);
-    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)evap,
-                                                (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
-                                                p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, clear));
+    DISPATCH_TLV(dtype, ref, vec, hipLaunchKernelGGL((k_adjust_ps_step<T, TL, V, STEP_U, REF>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                     dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const TL *)ta, (const TL *)evap,
+                                                     (const T *)PS, (const T *)FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps,
+                                                     p_ref, p_ref_field, adj_factor, full_column, apply_adj, st, clear));
     return PGW_OK;
 }
 
 static int launch_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const void *ta, const void *hus,
                                  const void *PS, const void *FIS, double p_ref, double *phi_out, int full_column,
-                                 const double *p_ref_field = nullptr) {
+                                 const double *p_ref_field = nullptr, bool ref = false) {
     int vec = pick_vec(ctx, dtype, ncol, {ta, hus, PS, FIS, phi_out}, 2);
     Levels lv = levels_of(ctx);
     Prof pr(ctx, PGW_K_PHI_REF_HYBRID);
-    DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_phi_ref_hybrid<T, V, STEP_U>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
-                                                dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)hus,
-                                                (const T *)PS, (const T *)FIS, p_ref, p_ref_field, phi_out,
-                                                full_column, ctx->d_status));
+    DISPATCH_TLV(dtype, ref, vec, hipLaunchKernelGGL((k_phi_ref_hybrid<T, V, STEP_U, REF>), dim3(nblocks((long long)ntime * ncol / V, BLOCK)),
+                                                     dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol, (const T *)ta, (const T *)hus,
+                                                     (const T *)PS, (const T *)FIS, p_ref, p_ref_field, phi_out,
+                                                     full_column, ctx->d_status));
     return PGW_OK;
 }
 
@@ -808,7 +826,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                        const void *dzg_b, const void *dzg_a, double x_hi, double x_new, double p_ref,
                        double adj_factor, double thresh, int max_n_iter, void *ps_pgw, void *hus_pgw, int *n_iter,
                        double *max_err_hist, int hist_len, int local_nplev = 0, const double *plev_file = nullptr,
-                       bool status_armed = false, int qv_done_levels = 0) {
+                       bool status_armed = false, int qv_done_levels = 0, bool ref = false) {
     const long long n2 = (long long)ntime * ncol;
     void *state = nullptr;
     int rc;
@@ -827,17 +845,18 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     } else {
         // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it).
         if (!status_armed && (rc = status_reset(ctx))) return rc;
-        launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column);
+        launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, p_ref, phi_era, full_column, nullptr, ref);
         HIPCHK(ctx, hipGetLastError());
         // status_armed (pgw_step03_file with the model-top check off): nothing is read back before the first pass;
         // the status block keeps the first error any kernel reported, in stream order, so the first pass's check
         // raises what an immediate check would have raised
         if (!status_armed && (rc = status_check(ctx))) return rc;
         // g * (time-interpolated zg delta at p_ref)   step_03:292-295
-        DISPATCH_T(dtype, {
+        DISPATCH_TLV(dtype, ref, 1, {
             DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
-            hipLaunchKernelGGL((k_dphi_clim<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi,
+            hipLaunchKernelGGL((k_dphi_clim<T, REF>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi,
                                delta_ps, adj_ps);                                       // + delta_ps = adj_ps = 0  :182-184
+            (void)V;
         });
     }
 
@@ -854,18 +873,19 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         DevStatus *cur = local ? ctx->d_status : blk[(it - 1) & 1];
         if (local) {
             // delta_ps += adj_ps ; per-column p_ref (never lower than last pass) ; g*zg at that level
-            DISPATCH_T(dtype, {
+            DISPATCH_TLV(dtype, ref, 1, {
                 DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
-                hipLaunchKernelGGL((k_local_p_ref<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, ptf, ctx->h_akN,
+                hipLaunchKernelGGL((k_local_p_ref<T, REF>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, ptf, ctx->h_akN,
                                    ctx->h_bkN, n2, (const T *)PS, delta_ps, adj_ps, z, ncol, it == 1 ? 1 : 0, pref_f,
                                    pref_idx, dphi, ctx->d_status);
+                (void)V;
             });
-            launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, 0.0, phi_era, full_column, pref_f);   // :280-287
+            launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, T, QV, PS, FIS, 0.0, phi_era, full_column, pref_f, ref);   // :280-287
             launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, 0.0, pref_f,
-                        adj_factor, full_column, 0);
+                        adj_factor, full_column, 0, nullptr, nullptr, ref);
         } else {
             launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_era, dphi, delta_ps, adj_ps, p_ref, nullptr,
-                        adj_factor, full_column, 1, cur, blk[it & 1]);
+                        adj_factor, full_column, 1, cur, blk[it & 1], ref);
         }
         HIPCHK(ctx, hipGetLastError());
         if ((rc = status_check(ctx, cur))) return rc;
@@ -886,9 +906,9 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         int vec = pick_vec(ctx, dtype, ncol, {PS, evap, ps_pgw, hus_pgw, delta_ps});
         Levels lv = levels_of(ctx);
         Prof pr(ctx, PGW_K_FINALIZE);
-        DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, V>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
-                                                    ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const T *)evap,
-                                                    (T *)ps_pgw, (T *)hus_pgw, qv_done_levels));
+        DISPATCH_TLV(dtype, ref, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, TL, V, REF>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                                         ctx->stream, lv, ntime, ncol, (const T *)PS, delta_ps, (const TL *)evap,
+                                                         (T *)ps_pgw, (TL *)hus_pgw, qv_done_levels));
     }
     HIPCHK(ctx, hipGetLastError());
     return PGW_OK;
@@ -926,7 +946,10 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     NEED(ctx, a->PS_out && a->T_out && a->QV_out && a->U_out && a->V_out, "output pointer is NULL");
     NEED(ctx, a->max_n_iter >= 1 && a->max_n_iter <= 1000, "bad max_n_iter");
     const bool exact = (a->x_hi == 0.0);
-    const size_t es = dtype == PGW_F64 ? 8 : 4;
+    const bool ref = a->ref_dtype != 0;
+    NEED(ctx, !ref || dtype == PGW_F32, "ref_dtype = 1 is the float32-file mode: dtype must be PGW_F32");
+    NEED(ctx, !ref || ctx->opt[PGW_OPT_QUAD], "ref_dtype = 1 needs the quad kernel (PGW_OPT_QUAD = 1)");
+    const size_t es = (dtype == PGW_F64 || ref) ? 8 : 4;      // element size of the PGW level arrays (evap, 4-D outputs)
     const int N = a->nlev;
     int rc;
     int qv_done = 0;          // leading levels whose final QV the quad kernel has already written
@@ -958,14 +981,15 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         for (int s = 0; s < a->nsoil; ++s) st.w[s] = exp(-a->soil_depth[s] / 2.8);      // step_03:140
         long long n = (long long)ntime * ncol;
         Prof pr(ctx, PGW_K_SURFACE);
-        DISPATCH_T(dtype, {
+        DISPATCH_TLV(dtype, ref, 1, {
             DeltaSrc<T> dsic{(const T *)a->siconc_b, exact ? nullptr : (const T *)a->siconc_a, a->x_hi, a->x_new};
             DeltaSrc<T> dts{(const T *)a->ts_b, exact ? nullptr : (const T *)a->ts_a, a->x_hi, a->x_new};
             DeltaSrc<T> dtos{(const T *)a->tos_b, exact ? nullptr : (const T *)a->tos_a, a->x_hi, a->x_new};
-            hipLaunchKernelGGL((k_surface_update_lerp<T>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, ntime, ncol, st,
+            hipLaunchKernelGGL((k_surface_update_lerp<T, REF>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, ntime, ncol, st,
                                (const T *)a->FR_SEA_ICE, dsic, dtos, dts, (const T *)a->FR_LAND, (const T *)a->ts_clim,
                                (const T *)a->T_SKIN, (const T *)a->T_SO, (T *)a->FR_SEA_ICE_out, (T *)a->T_SKIN_out,
                                (T *)a->T_SO_out);
+            (void)V;
         });
     }
 
@@ -984,12 +1008,12 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
             {
                 Prof pr(ctx, PGW_K_QUAD_DELTA);
 #define LAUNCH_QUAD(OT, LERP_)                                                                                        \
-                    hipLaunchKernelGGL((k_delta_quad<T, QUAD_U, 128, OT, LERP_>), dim3(nblocks((long long)ntime * ncol, 128)), \
+                    hipLaunchKernelGGL((k_delta_quad<T, TL, QUAD_U, 128, OT, LERP_, REF>), dim3(nblocks((long long)ntime * ncol, 128)), \
                                        dim3(128), qlds, ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T,     \
                                        (const T *)a->QV, (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, \
-                                       dwd, check_top, (T *)a->T_out, (T *)evap, (T *)a->hur_pgw_out, (T *)a->U_out,      \
-                                       (T *)a->V_out, (T *)a->QV_out, qv_done, ctx->n_pure, ctx->d_status)
-                DISPATCH_T(dtype, {
+                                       dwd, check_top, (TL *)a->T_out, (TL *)evap, (TL *)a->hur_pgw_out, (TL *)a->U_out,      \
+                                       (TL *)a->V_out, (TL *)a->QV_out, qv_done, ctx->n_pure, ctx->d_status)
+                DISPATCH_TLV(dtype, ref, 1, {
                     PairSrc<T> dth{{(const T *)a->ta_b, exact ? nullptr : (const T *)a->ta_a, a->x_hi, a->x_new},
                                    {(const T *)a->hur_b, exact ? nullptr : (const T *)a->hur_a, a->x_hi, a->x_new}};
                     PairSrc<T> ds{{(const T *)a->tas_b, exact ? nullptr : (const T *)a->tas_a, a->x_hi, a->x_new},
@@ -998,10 +1022,11 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                     PairSrc<T> dwd{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
                                    {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
                     // arrays below 4 GiB (a 0.25 deg L137 field is 1.1 GB): 32-bit byte offsets from uniform bases
-                    const bool o32 = (unsigned long long)ntime * (N > S ? N : S) * ncol * sizeof(T) < (1ull << 32);
+                    const bool o32 = (unsigned long long)ntime * (N > S ? N : S) * ncol * sizeof(TL) < (1ull << 32);
                     // LERP: the instant lies between two records (false: it is a record, `exact`)
                     if (o32) { if (exact) LAUNCH_QUAD(boff32, false); else LAUNCH_QUAD(boff32, true); }
                     else { if (exact) LAUNCH_QUAD(boff64, false); else LAUNCH_QUAD(boff64, true); }
+                    (void)V;
                 });
 #undef LAUNCH_QUAD
             }
@@ -1053,7 +1078,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                      a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a, a->x_hi,
                      a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
                      a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev,
-                     !check_top && !a->local_p_ref, qv_done);
+                     !check_top && !a->local_p_ref, qv_done, ref);
     a->levels_touched = ctx->last_levels_touched;
     return rc;
 }

@@ -230,6 +230,27 @@ __device__ __forceinline__ double e_to_q(double vapp, double pa) {         // :6
 __device__ __forceinline__ double q_to_rh(double hus, double pa, double ta) {   // :107-116
     return (q_to_e(hus, pa) / esat_mixed(ta)) * 100;
 }
+// ---- reference-dtype mode: RELHUM of a float32 ERA state as numpy's promotion evaluates functions.py:58-116 ----
+// e_sat of a float32 temperature is float32 throughout (alpha = full_like(ta): :95-98; a1*np.exp(a3*(ta-T0)/(ta-a4)):
+// :88 with the python floats taken as float32 scalars); every operation below is one IEEE float32 operation except
+// expf (<= 1 ulp here; numpy's SIMD float32 exp differs from it by a few float32 ulp - the reference's own last bits).
+__device__ __forceinline__ float esat_x_f32(float ta, float a3, float a4) {
+    return 611.21f * expf(a3 * (ta - 273.16f) / (ta - a4));
+}
+__device__ __forceinline__ float esat_mixed_f32(float ta) {
+    const float T0 = 273.16f, Ti = 250.16f;
+    float alpha = __builtin_nanf("");
+    if (ta >= T0) alpha = 1.0f;
+    if (ta <= Ti) alpha = 0.0f;
+    if (ta < T0 && ta > Ti) { const float r = (ta - Ti) / 23.0f; alpha = r * r; }   // (T0 - Ti) = 23.000000000000028 -> 23.0f
+    return alpha * esat_x_f32(ta, 17.502f, 32.19f) + (1.0f - alpha) * esat_x_f32(ta, 22.587f, -0.7f);
+}
+// hus float32, pa float64 (ak/bk are float64): hus*pa is float64, the denominator CON_MW_MD + 0.378*hus float32 (:63)
+__device__ __forceinline__ double q_to_rh_f32(float hus, double pa, float ta) {
+    const double vapp = (double)hus * pa / (double)(0.622f + 0.378f * hus);
+    return (vapp / (double)esat_mixed_f32(ta)) * 100;
+}
+
 __device__ __forceinline__ double div_by_100(double x) { return SharedDivisor(100.0, 0.01).divide(x); }
 __device__ __forceinline__ double rh_to_e(double hur, double ta) {         // :123
     return div_by_100(hur) * esat_mixed(ta);

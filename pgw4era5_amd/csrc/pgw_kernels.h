@@ -152,9 +152,21 @@ struct GeoAcc {            // per-column running state of the upward scan
     double phi;            // phi at the lower half level of the current layer
     double p_lo, lnp_lo;   // pressure / ln p at that half level
     double dmin;           // smallest non-negative p_hl - p_ref so far
-    double phi_s, tv_s, lnp_s;
+    double phi_s, rtv_s, lnp_s;   // phi, CON_RD*tv and ln p captured at the candidate k*
     int kstar;             // -1 = none yet
 };
+
+// Reference-dtype mode (REF, float32 ERA5 files): `phi_hl` is created from the float32
+// `zgs` (functions.py:141), so every assignment phi_hl[l] = ... (:149-152) rounds to float32; `tav` and `CON_RD * tav`
+// are float32 products for the float32 ERA state (:144, :150).  All of these are single IEEE operations, reproduced
+// exactly: cvt f64->f32->f64 for the store, v_mul_f32 / v_add_f32 for the products (-ffp-contract=off).
+template <bool REF>
+__device__ __forceinline__ double phi_store(double x) { return REF ? (double)(float)x : x; }
+// CON_RD * (ta * (1 + 0.61 * hus)) for float32 ta, hus as numpy evaluates it: python floats become float32 scalars
+__device__ __forceinline__ double rd_tv_f32(double t, double q) {
+    const float tv = (float)t * (1.0f + 0.61f * (float)q);       // :144
+    return (double)(287.05f * tv);                               // :150  CON_RD * tav.sel(...)
+}
 
 __device__ __forceinline__ void geo_init(GeoAcc &a, double zgs, double p_bottom) {
     a.phi = zgs;
@@ -162,17 +174,18 @@ __device__ __forceinline__ void geo_init(GeoAcc &a, double zgs, double p_bottom)
     a.lnp_lo = pgw_log(a.p_lo);
     a.dmin = __builtin_inf();
     a.kstar = -1;
-    a.phi_s = a.tv_s = a.lnp_s = 0.0;
+    a.phi_s = a.rtv_s = a.lnp_s = 0.0;
 }
-// process layer l (between half levels l and l+1); p_top = pa_hl[l] raw
-__device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double tv, double p_top, double p_ref) {
+// process layer l (between half levels l and l+1); rtv = CON_RD * tv of the layer; p_top = pa_hl[l] raw
+template <bool REF = false>
+__device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double rtv, double p_top, double p_ref) {
     double d = a.p_lo - p_ref;                        // candidate k = l+1         :160-161
     if (d >= 0 && d <= a.dmin) {
-        a.dmin = d; a.kstar = l + 1; a.phi_s = a.phi; a.tv_s = tv; a.lnp_s = a.lnp_lo;
+        a.dmin = d; a.kstar = l + 1; a.phi_s = a.phi; a.rtv_s = rtv; a.lnp_s = a.lnp_lo;
     }
     double p_hi = fix_p(p_top);                       // :135
     double lnp_hi = pgw_log_f3(p_hi);                   // the log of the level loops of geopot / phi_ref / pass kernels
-    a.phi = a.phi + (CON_RD * tv) * (a.lnp_lo - lnp_hi);   // :149-152, dlnpa :136-138
+    a.phi = phi_store<REF>(a.phi + rtv * (a.lnp_lo - lnp_hi));   // :149-152, dlnpa :136-138
     a.p_lo = p_hi; a.lnp_lo = lnp_hi;
 }
 // returns phi_ref; reports errors
@@ -181,7 +194,7 @@ __device__ __forceinline__ double geo_finish(GeoAcc &a, double p_ref, DevStatus 
     if (d >= 0 && d <= a.dmin) a.kstar = 0;
     if (a.kstar < 0) { report(st, 13 /*PGW_ERR_PREF_BELOW_SURFACE*/, col); return __builtin_nan(""); }
     if (a.kstar == 0) { report(st, 14 /*PGW_ERR_PREF_AT_TOP*/, col); return __builtin_nan(""); }
-    return a.phi_s - (CON_RD * a.tv_s) * (pgw_log(p_ref) - a.lnp_s);    // :174-179
+    return a.phi_s - a.rtv_s * (pgw_log(p_ref) - a.lnp_s);    // :174-179
 }
 
 // TO = type of the phi_ref output (T for the signature-faithful call, double for the loop state)
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_integ_geopot(int nlev, int ntime, lon
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 double tv = t[u][v] * (1 + 0.61 * q[u][v]);          // :144
-                geo_layer(acc[v], l - u, tv, p[u][v], pref[v]);
+                geo_layer(acc[v], l - u, CON_RD * tv, p[u][v], pref[v]);
             }
         }
         if (!full_column) {
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_integ_geopot(int nlev, int ntime, lon
         loadv<T, V>(pt + (long long)l * ncol, t);
         loadv<T, V>(pq + (long long)l * ncol, q);
 #pragma unroll
-        for (int v = 0; v < V; ++v) geo_layer(acc[v], l, t[v] * (1 + 0.61 * q[v]), p[v], pref[v]);
+        for (int v = 0; v < V; ++v) geo_layer(acc[v], l, CON_RD * (t[v] * (1 + 0.61 * q[v])), p[v], pref[v]);
     }
 done:
     double r[V];
@@ -265,9 +278,11 @@ done:
 // (second field = vapour pressure e, q = e_to_q(e, pa)) and by phi_ref of the ERA state (second
 // field = QV itself).  Levels are processed in chunks of U with the next chunk's 2*U row loads
 // already in flight (software pipeline; ~2*U KiB per wave outstanding).
-template <typename T, int V, int U, bool SECOND_IS_Q>
-__device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt, long long ncol, const T *__restrict__ pt,
-                                             const T *__restrict__ pe, const double (&ps)[V], const double (&z)[V],
+// TL = storage type of the two level arrays.  REF (reference-dtype mode, float32 files): phi rounded to float32 per
+// level; for the ERA state (SECOND_IS_Q, float32 T and QV) tav and CON_RD*tav are float32 products.
+template <typename TL, int V, int U, bool SECOND_IS_Q, bool REF>
+__device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt, long long ncol, const TL *__restrict__ pt,
+                                             const TL *__restrict__ pe, const double (&ps)[V], const double (&z)[V],
                                              const double (&pref)[V], int full_column, DevStatus *st, long long c2,
                                              double (&phi_ref)[V], double (&tlow)[V], int &touched) {
     const int N = lv.nlev;
@@ -285,8 +300,8 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         int lu = (N - 1 - u) > 0 ? (N - 1 - u) : 0;
-        loadv<T, V>(pt + (long long)lu * ncol, tn[u]);
-        loadv<T, V>(pe + (long long)lu * ncol, en[u]);
+        loadv<TL, V>(pt + (long long)lu * ncol, tn[u]);
+        loadv<TL, V>(pe + (long long)lu * ncol, en[u]);
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) tlow[v] = tn[0][v];             // ta at the lowest full level, :303
@@ -300,8 +315,8 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int lu = (l - U - u) > 0 ? (l - U - u) : 0;
-                loadv<T, V>(pt + (long long)lu * ncol, tn[u]);
-                loadv<T, V>(pe + (long long)lu * ncol, en[u]);
+                loadv<TL, V>(pt + (long long)lu * ncol, tn[u]);
+                loadv<TL, V>(pe + (long long)lu * ncol, en[u]);
             }
         }
 #pragma unroll
@@ -311,11 +326,15 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
                 double am = lt.akm[lc], bm = lt.bkm[lc], a = lt.ak[lc], b = lt.bk[lc];
 #pragma unroll
                 for (int v = 0; v < V; ++v) {
-                    double q;
-                    if (SECOND_IS_Q) q = e[u][v];
-                    else q = e_to_q(e[u][v], am + ps[v] * bm);      // :196, :262-266
-                    double tv = t[u][v] * (1 + 0.61 * q);           // functions.py:144
-                    geo_layer(acc[v], lc, tv, a + ps[v] * b, pref[v]);
+                    double rtv;
+                    if (SECOND_IS_Q) {
+                        if (REF) rtv = rd_tv_f32(t[u][v], e[u][v]);                    // float32 T, QV: float32 products
+                        else rtv = CON_RD * (t[u][v] * (1 + 0.61 * e[u][v]));          // functions.py:144
+                    } else {
+                        double q = e_to_q(e[u][v], am + ps[v] * bm);                   // :196, :262-266
+                        rtv = CON_RD * (t[u][v] * (1 + 0.61 * q));
+                    }
+                    geo_layer<REF>(acc[v], lc, rtv, a + ps[v] * b, pref[v]);
                 }
                 touched += V;
             }
@@ -331,9 +350,16 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
     for (int v = 0; v < V; ++v) phi_ref[v] = geo_finish(acc[v], pref[v], st, c2 + v);
 }
 
-template <typename T, int V, int U>
+// step_03:192-193.  REF: delta_ps is a float32 array updated in place (`delta_ps += adj_ps` casts the float64 sum back,
+// step_03:182-192) and ps_pgw = PS + delta_ps is a float32 sum; the fp64 state array then holds float32 values.
+template <bool REF>
+__device__ __forceinline__ double next_delta_ps(double dps, double adj) { return REF ? (double)(float)(dps + adj) : dps + adj; }
+template <bool REF>
+__device__ __forceinline__ double ps_of(double ps0, double dps) { return REF ? (double)((float)ps0 + (float)dps) : ps0 + dps; }
+
+template <typename T, typename TL, int V, int U, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, long long ncol,
-                                                          const T *__restrict__ ta, const T *__restrict__ evap,
+                                                          const TL *__restrict__ ta, const TL *__restrict__ evap,
                                                           const T *__restrict__ PS, const T *__restrict__ FIS,
                                                           const double *__restrict__ phi_ref_era,
                                                           const double *__restrict__ dphi_clim,
@@ -371,17 +397,19 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            if (apply_adj) dps[v] = dps[v] + adj[v];        // step_03:192 (already applied by k_local_p_ref otherwise)
-            ps[v] = ps0[v] + dps[v];                        // :193
+            if (apply_adj) dps[v] = next_delta_ps<REF>(dps[v], adj[v]);   // step_03:192 (already applied by k_local_p_ref otherwise)
+            ps[v] = ps_of<REF>(ps0[v], dps[v]);                           // :193
         }
         if (apply_adj) storev<double, V>(delta_ps + c2, dps);
-        scan_columns<T, V, U, false>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, evap + ix.t * N * ncol + ix.c, ps, z, pref,
-                                     full_column, st, c2, phi_ref, tlow, touched);
+        scan_columns<TL, V, U, false, REF>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, evap + ix.t * N * ncol + ix.c, ps, z, pref,
+                                           full_column, st, c2, phi_ref, tlow, touched);
         double nadj[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             double err = (phi_ref[v] - phi_ref_era[c2 + v]) - dphi_clim[c2 + v];      // :289,298
-            nadj[v] = -adj_factor * ps[v] / (CON_RD * tlow[v]) * err;                 // :301-304
+            // :301-304.  REF: `-adj_factor * ps_pgw` is a float32 product (python float x float32 array)
+            const double fps = REF ? (double)((float)(-adj_factor) * (float)ps[v]) : -adj_factor * ps[v];
+            nadj[v] = fps / (CON_RD * tlow[v]) * err;
             double ae = fabs(err);
             if (ae == ae) amax = fmax(amax, ae);                                      // :308 skipna
         }
@@ -410,7 +438,7 @@ __global__ __launch_bounds__(BLOCK) void k_adjust_ps_step(Levels lv, int ntime, 
 // phi_ref of the ERA state from (T, QV, PS, FIS) with the hybrid pressure rebuilt in registers
 // (step_03:280-287 with pa_hl_era of :64-66): no 4-D pressure array, and like the pass kernel it
 // only reads the levels below p_ref.
-template <typename T, int V, int U>
+template <typename T, int V, int U, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_phi_ref_hybrid(Levels lv, int ntime, long long ncol,
                                                           const T *__restrict__ ta, const T *__restrict__ hus,
                                                           const T *__restrict__ PS, const T *__restrict__ FIS,
@@ -433,17 +461,17 @@ __global__ __launch_bounds__(BLOCK) void k_phi_ref_hybrid(Levels lv, int ntime, 
 #pragma unroll
         for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
     }
-    scan_columns<T, V, U, true>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, hus + ix.t * N * ncol + ix.c, ps, z, pref,
-                                full_column, st, c2, phi_ref, tlow, touched);
+    scan_columns<T, V, U, true, REF>(lv, lt, ncol, ta + ix.t * N * ncol + ix.c, hus + ix.t * N * ncol + ix.c, ps, z, pref,
+                                     full_column, st, c2, phi_ref, tlow, touched);
     storev<double, V>(phi_out + c2, phi_ref);
 }
 
 // final outputs of the loop: ps_pgw = PS + delta_ps (step_03:193,369), hus_pgw from e (:262-266,370)
-template <typename T, int V>
+template <typename T, typename TL, int V, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime, long long ncol,
                                                            const T *__restrict__ PS, const double *__restrict__ delta_ps,
-                                                           const T *__restrict__ evap, T *__restrict__ ps_out,
-                                                           T *__restrict__ hus_out, int l_start) {
+                                                           const TL *__restrict__ evap, T *__restrict__ ps_out,
+                                                           TL *__restrict__ hus_out, int l_start) {
     __shared__ double s_lev[LEVTAB_DOUBLES];
     LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -455,7 +483,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
     loadv<T, V>(PS + c2, ps0);
     loadv<double, V>(delta_ps + c2, dps);
 #pragma unroll
-    for (int v = 0; v < V; ++v) ps[v] = ps0[v] + dps[v];
+    for (int v = 0; v < V; ++v) ps[v] = ps_of<REF>(ps0[v], dps[v]);
     if (ps_out) storev<T, V>(ps_out + c2, ps);
     if (hus_out) {
         const int N = lv.nlev;
@@ -463,11 +491,11 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
 #pragma unroll 4
         for (int l = l_start; l < N; ++l) {            // levels < l_start were written by k_delta_quad
             double e[V], r[V];
-            loadv<T, V>(evap + base + (long long)l * ncol, e);
+            loadv<TL, V>(evap + base + (long long)l * ncol, e);
             double am = lt.akm[l], bm = lt.bkm[l];
 #pragma unroll
             for (int v = 0; v < V; ++v) r[v] = e_to_q(e[v], am + ps[v] * bm);
-            storev<T, V>(hus_out + base + (long long)l * ncol, r);
+            storev<TL, V>(hus_out + base + (long long)l * ncol, r);
         }
     }
 }
@@ -613,22 +641,27 @@ template <typename T>
 struct DeltaSrc {
     const T *b, *a;          // bracketing records (a may be null)
     double x_hi, x_new;
+    // REF (reference-dtype mode): scipy's interp1d._call_linear takes y_hi - y_lo in the dtype of the file (float32 deltas:
+    // one float32 subtraction), slope and result in float64 (functions.py:288-292 through xarray .interp)
+    template <bool REF = false>
     __device__ __forceinline__ double get(long long off) const {
-        double vb = (double)b[off];
-        if (!a) return vb;                                        // :282-283
-        double va = (double)a[off];
-        return (va - vb) / x_hi * x_new + vb;                     // :288-292 (scipy interp1d linear)
+        const T rb = b[off];
+        if (!a) return (double)rb;                                // :282-283
+        const T ra = a[off];
+        const double diff = REF ? (double)(T)(ra - rb) : (double)ra - (double)rb;
+        return diff / x_hi * x_new + (double)rb;                  // :288-292 (scipy interp1d linear)
     }
     // same, addressed by byte offset (ld_off); the division by the kernel-wide x_hi goes through a reciprocal the
     // caller computed once (SharedDivisor: same quotient bits)
     // LERP is the compile-time form of `a != nullptr` (all records of a file share the instant, so it is one
     // property of the launch): no per-source null test - those tests were uniform 64-bit masks kept in spilled SGPRs
-    template <bool LERP, typename O>
+    template <bool LERP, bool REF, typename O>
     __device__ __forceinline__ double get_at(O byte_off, const SharedDivisor &by_x_hi) const {
-        double vb = (double)ld_off(b, byte_off);
-        if (!LERP) return vb;
-        double va = (double)ld_off(a, byte_off);
-        return by_x_hi.divide(va - vb) * x_new + vb;
+        const T rb = ld_off(b, byte_off);
+        if (!LERP) return (double)rb;
+        const T ra = ld_off(a, byte_off);
+        const double diff = REF ? (double)(T)(ra - rb) : (double)ra - (double)rb;
+        return by_x_hi.divide(diff) * x_new + (double)rb;
     }
 };
 
@@ -974,15 +1007,18 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
 #ifndef QUAD_MINW
 #define QUAD_MINW 3
 #endif
-template <typename T, int U, int TPB, typename O, bool LERP>
+// TO = storage type of the 4-D outputs.  REF (reference-dtype mode; T = float, TO = double): what numpy's promotion
+// computes on float32 files - RELHUM of the ERA state through the float32 e_sat chain
+// (q_to_rh_f32), float32 record differences in the time interpolation, era (float32) + delta (float64) = float64 outputs.
+template <typename T, typename TO, int U, int TPB, typename O, bool LERP, bool REF>
 __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                        const T *__restrict__ fT, const T *__restrict__ fQ,
                                                        const T *__restrict__ fU, const T *__restrict__ fV,
                                                        const T *__restrict__ PS,
                                                        PairSrc<T> dth, PairSrc<T> dsfc, DeltaSrc<T> psh, PairSrc<T> dw,
-                                                       int check_top, T *__restrict__ oT, T *__restrict__ oE,
-                                                       T *__restrict__ oHur, T *__restrict__ oU, T *__restrict__ oV,
-                                                       T *__restrict__ oQ, int n_pure, int n_pure_lv, DevStatus *st) {
+                                                       int check_top, TO *__restrict__ oT, TO *__restrict__ oE,
+                                                       TO *__restrict__ oHur, TO *__restrict__ oU, TO *__restrict__ oV,
+                                                       TO *__restrict__ oQ, int n_pure, int n_pure_lv, DevStatus *st) {
     // n_pure > 0: the first n_pure full levels are pure-pressure levels (bkm == 0): their pressure does not depend
     // on the surface pressure, so the final QV = e_to_q(e, akm) (step_03:262-266,370) is written here already
     // (instead of e, which only the levels below p_ref and k_finalize_ps_hus need) and the finalize kernel skips them.
@@ -1017,12 +1053,14 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
         const O row = (O)((unsigned long long)ncol * sizeof(T));
         const O dbase = (O)((unsigned long long)(t * S * ncol + c) * sizeof(T));
         const O base = (O)((unsigned long long)(t * N * ncol + c) * sizeof(T));
+        const O orow = (O)((unsigned long long)ncol * sizeof(TO));          // outputs: their own element size
+        const O obase = (O)((unsigned long long)(t * N * ncol + c) * sizeof(TO));
         const double ps = (double)PS[flat];
         const bool ps_finite = __builtin_fabs(ps) <= 1.7976931348623157e308;   // false for NaN, +-inf
         // ---- surface insertion for ta / hur (replace_delta_sfc, functions.py:343-366)
         int ksfc = -1;
         bool fill = false;
-        double pshv = psh.get(flat), sfa = dsfc.a.get(flat), sfb = dsfc.b.get(flat);
+        double pshv = psh.template get<REF>(flat), sfa = dsfc.a.template get<REF>(flat), sfb = dsfc.b.template get<REF>(flat);
         {
             bool bad = false;
             if (pshv > pt.pmax) ksfc = S - 1;                                  // :356-359
@@ -1053,26 +1091,30 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
             if (ci1 == i1) return;
             O o = dbase + (O)(S - 1 - i1) * row;
             if (ci1 + 1 == i1) { a_lo = a_hi; b_lo = b_hi; }
-            else { a_lo = is_sfc(i1) ? sfa : sTa.template get_at<LERP>(o, by_x_hi); b_lo = is_sfc(i1) ? sfb : sHur.template get_at<LERP>(o, by_x_hi); }
+            else { a_lo = is_sfc(i1) ? sfa : sTa.template get_at<LERP, REF>(o, by_x_hi); b_lo = is_sfc(i1) ? sfb : sHur.template get_at<LERP, REF>(o, by_x_hi); }
             int ih = (i1 + 1 < S) ? i1 + 1 : i1;
             O oh = dbase + (O)(S - 1 - ih) * row;
-            a_hi = is_sfc(ih) ? sfa : sTa.template get_at<LERP>(oh, by_x_hi);
-            b_hi = is_sfc(ih) ? sfb : sHur.template get_at<LERP>(oh, by_x_hi);
+            a_hi = is_sfc(ih) ? sfa : sTa.template get_at<LERP, REF>(oh, by_x_hi);
+            b_hi = is_sfc(ih) ? sfb : sHur.template get_at<LERP, REF>(oh, by_x_hi);
             ci1 = i1;
         };
         auto fetch2 = [&](int i1) {
             if (ci2 == i1) return;
             O o = dbase + (O)(S - 1 - i1) * row;
             if (ci2 + 1 == i1) { c_lo = c_hi; d_lo = d_hi; }
-            else { c_lo = sUa.template get_at<LERP>(o, by_x_hi); d_lo = sVa.template get_at<LERP>(o, by_x_hi); }
+            else { c_lo = sUa.template get_at<LERP, REF>(o, by_x_hi); d_lo = sVa.template get_at<LERP, REF>(o, by_x_hi); }
             int ih = (i1 + 1 < S) ? i1 + 1 : i1;
             O oh = dbase + (O)(S - 1 - ih) * row;
-            c_hi = sUa.template get_at<LERP>(oh, by_x_hi);
-            d_hi = sVa.template get_at<LERP>(oh, by_x_hi);
+            c_hi = sUa.template get_at<LERP, REF>(oh, by_x_hi);
+            d_hi = sVa.template get_at<LERP, REF>(oh, by_x_hi);
             ci2 = i1;
         };
         int j1 = 0, j2 = 0;
         double xprev = -__builtin_inf();
+        // y_hi - y_lo of the column interpolation (functions.py:575-578): numba takes it in the delta's dtype - float64
+        // after a time interpolation, the file's float32 when the instant is a record (REF && !LERP)
+        auto ydiff = [](double hi, double lo) -> double {
+            return (REF && !LERP) ? (double)((float)hi - (float)lo) : hi - lo; };
         // ---- level loop, chunks of U levels with the next chunk's 4*U rows in flight
         double nT[U], nQ[U], nU[U], nV[U];
 #pragma unroll
@@ -1121,8 +1163,8 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         double x1 = s_lnp[p1], x2 = s_lnp[p2];
                         dxp = x - x1;
                         by_Dp = SharedDivisor(x2 - x1);                            // x1 < x < x2: finite, positive
-                        dc = c_lo + by_Dp.divide(dxp * (c_hi - c_lo));
-                        dd = d_lo + by_Dp.divide(dxp * (d_hi - d_lo));
+                        dc = c_lo + by_Dp.divide(dxp * ydiff(c_hi, c_lo));
+                        dd = d_lo + by_Dp.divide(dxp * ydiff(d_hi, d_lo));
                     }
                     // ta, hur on the axis modified by the surface insertion (level ksfc moved to ps_hist, :362-365).
                     // Source levels below index ksfc are untouched, so while the plain scan stands at j2 < ksfc the
@@ -1132,8 +1174,8 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         fetch1(p1);
                         da = a_lo; db = b_lo;
                         if (p1 != p2) {
-                            da = a_lo + by_Dp.divide(dxp * (a_hi - a_lo));
-                            db = b_lo + by_Dp.divide(dxp * (b_hi - b_lo));
+                            da = a_lo + by_Dp.divide(dxp * ydiff(a_hi, a_lo));
+                            db = b_lo + by_Dp.divide(dxp * ydiff(b_hi, b_lo));
                         }
                     } else {
                         // j1 may lag behind (it only moves here); targets ascend, so resuming from it finds the same index
@@ -1152,21 +1194,23 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                             double x1 = sx1(i1), x2 = sx1(i2);
                             const double dx = x - x1;
                             const SharedDivisor by_Dx(x2 - x1);
-                            da = a_lo + by_Dx.divide(dx * (a_hi - a_lo));
-                            db = b_lo + by_Dx.divide(dx * (b_hi - b_lo));
+                            da = a_lo + by_Dx.divide(dx * ydiff(a_hi, a_lo));
+                            db = b_lo + by_Dx.divide(dx * ydiff(b_hi, b_lo));
                         }
                     }
-                    const O o = base + (O)l * row;
-                    st_off(oU, o, (T)(cU[u] + dc));                                // step_03:170-173
-                    st_off(oV, o, (T)(cV[u] + dd));
-                    double rh_era = q_to_rh(cQ[u], pa, cT[u]);                     // step_03:91-94
+                    const O o = obase + (O)l * orow;
+                    st_off(oU, o, (TO)(cU[u] + dc));                               // step_03:170-173
+                    st_off(oV, o, (TO)(cV[u] + dd));
+                    double rh_era;                                                 // step_03:91-94
+                    if (REF) rh_era = q_to_rh_f32((float)cQ[u], pa, (float)cT[u]);
+                    else rh_era = q_to_rh(cQ[u], pa, cT[u]);
                     double ta_pgw = cT[u] + da;
                     double hur_pgw = rh_era + db;
-                    st_off(oT, o, (T)ta_pgw);
+                    st_off(oT, o, (TO)ta_pgw);
                     double e_pgw = rh_to_e(hur_pgw, ta_pgw);                       // functions.py:123
-                    if (l < n_pure) st_off(oQ, o, (T)e_to_q(e_pgw, pa));           // pa == akm[l] for every finite ps
-                    else st_off(oE, o, (T)e_pgw);
-                    if (oHur) st_off(oHur, o, (T)hur_pgw);
+                    if (l < n_pure) st_off(oQ, o, (TO)e_to_q(e_pgw, pa));          // pa == akm[l] for every finite ps
+                    else st_off(oE, o, (TO)e_pgw);
+                    if (oHur) st_off(oHur, o, (TO)hur_pgw);
                 }
             }
         }
@@ -1463,7 +1507,7 @@ __global__ __launch_bounds__(BLOCK) void k_integrate_tos(long long n, const T *_
 // p_ref_inp = None (step_03:219-253 with determine_p_ref, functions.py:583-598): per column the first
 // plev (file order) with 0.95*ps_era > p and 0.95*ps_pgw > p, never below the previous pass's choice;
 // also applies delta_ps += adj_ps (step_03:192) and gathers g * zg-delta at the chosen level (:292-295).
-template <typename T>
+template <typename T, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_local_p_ref(PlevTable pt /* p[] in FILE order here */, double akN, double bkN,
                                                        long long n, const T *__restrict__ PS,
                                                        double *__restrict__ delta_ps, const double *__restrict__ adj_ps,
@@ -1472,11 +1516,11 @@ __global__ __launch_bounds__(BLOCK) void k_local_p_ref(PlevTable pt /* p[] in FI
                                                        double *__restrict__ dphi, DevStatus *st) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    double dps = delta_ps[i] + adj_ps[i];                           // step_03:192
+    double dps = next_delta_ps<REF>(delta_ps[i], adj_ps[i]);        // step_03:192
     delta_ps[i] = dps;
     double ps0 = (double)PS[i];
     double p_min_era = (akN + ps0 * bkN) * 0.95;                    // :227-228
-    double p_min_pgw = (akN + (ps0 + dps) * bkN) * 0.95;            // :229-230
+    double p_min_pgw = (akN + ps_of<REF>(ps0, dps) * bkN) * 0.95;   // :229-230
     double p = __builtin_nan("");
     int k = -1;
     for (int j = 0; j < pt.n; ++j) {
@@ -1490,7 +1534,7 @@ __global__ __launch_bounds__(BLOCK) void k_local_p_ref(PlevTable pt /* p[] in FI
     p_ref[i] = p;
     p_idx[i] = k;
     long long t = i / ncol, c = i - t * ncol;
-    dphi[i] = zg.get((t * pt.n + k) * ncol + c) * CON_G;            // step_03:292-295
+    dphi[i] = zg.template get<REF>((t * pt.n + k) * ncol + c) * CON_G;            // step_03:292-295
 }
 
 // step_03:192-193
@@ -1505,18 +1549,22 @@ __global__ __launch_bounds__(BLOCK) void k_update_ps(long long n, const T *__res
 }
 
 // g * time-interpolated zg delta at p_ref -> fp64 loop constant (step_03:292-295)
-template <typename T>
+// REF: a record that needed no time interpolation stays float32 (functions.py:282-283) and `* CON_G` is a float32 product
+template <typename T, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z, double g, double *__restrict__ out,
                                                      double *__restrict__ zero_a, double *__restrict__ zero_b) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) {
-        out[i] = z.get(i) * g;
+        if (REF && !z.a) out[i] = (double)((float)z.b[i] * (float)g);
+        else out[i] = z.template get<REF>(i) * g;
         if (zero_a) { zero_a[i] = 0.0; zero_b[i] = 0.0; }          // delta_ps, adj_ps of the loop start (step_03:182-184)
     }
 }
 
 // surface riders with the time lerp of the three 2-D deltas fused in (step_03:103-146)
-template <typename T>
+// REF: the sea-ice fraction the blend sees is the float32 value stored back into the file's array (step_03:105-107), and
+// `ice + land`, `1 - frac` are float32 operations on the file's float32 fractions (functions.py:1183-1184)
+template <typename T, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long long ncol, SoilTable soil,
                                                                const T *__restrict__ sic, DeltaSrc<T> dsic, DeltaSrc<T> dtos,
                                                                DeltaSrc<T> dts, const T *__restrict__ land,
@@ -1528,21 +1576,29 @@ __global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long l
     if (i >= n) return;
     long long t = i / ncol, c = i - t * ncol;
     auto ice_of = [&](long long k) -> double {
-        double s0 = (double)sic[k], d0 = dsic.get(k);
+        double s0 = (double)sic[k], d0 = dsic.template get<REF>(k);
         double v = s0 + d0 / 100;                                     // step_03:105
         v = fmin(fmax(v, 0.0), 1.0);                                  // :106-107
         if (s0 != s0 || d0 != d0) v = __builtin_nan("");              // np.clip keeps NaN
-        return v;
+        return REF ? (double)(T)v : v;
     };
     double ice = ice_of(i);
     sic_out[i] = (T)ice;
     double ice0 = (t == 0) ? ice : ice_of(c);                         // .isel(time=0), :121-122
-    double tos = dtos.get(i), ts = dts.get(i);
+    double tos = dtos.template get<REF>(i), ts = dts.template get<REF>(i);
     double comb = ts;                                                 // functions.py:1180-1181
     if (ice0 == ice0 && tos == tos) {                                 // :1173
-        double fr = fmin(fmax(ice0 + (double)land[c], 0.0), 1.0);     // :1183
-        if ((double)land[c] != (double)land[c]) fr = __builtin_nan("");
-        comb = fr * ts + (1 - fr) * tos;                              // :1184
+        double fr, omf;
+        if (REF) {
+            float f = fminf(fmaxf((float)ice0 + (float)land[c], 0.0f), 1.0f);
+            if ((float)land[c] != (float)land[c]) f = __builtin_nanf("");
+            fr = (double)f; omf = (double)(1.0f - f);
+        } else {
+            fr = fmin(fmax(ice0 + (double)land[c], 0.0), 1.0);        // :1183
+            if ((double)land[c] != (double)land[c]) fr = __builtin_nan("");
+            omf = 1 - fr;
+        }
+        comb = fr * ts + omf * tos;                                   // :1184
     }
     tskin_out[i] = (T)((double)tskin[i] + comb);                      // step_03:124
     if (tso_out) {

@@ -31,3 +31,12 @@ adj_factor = 0.95
 thresh_phi_ref_max_error = 0.15
 max_n_iter = 20
 i_reinterp = 0
+
+# ---- not in the reference: arithmetic on float32 ERA5 files ----------------------------------
+# 'reference': what the reference computes on float32 files - numpy's promotion puts float32 roundings into it
+#     (phi_hl stored in FIS' dtype, functions.py:141,149; float32 tav / e_sat of the ERA state; float32 delta_ps and
+#     ps_pgw, step_03:182-193) and writes T, QV, U, V as float64 (`era + delta`, step_03:170-173).  The kernels
+#     reproduce those roundings (pgw_file_args.ref_dtype = 1), so iteration count and PS follow the reference.
+# 'fast': float64 arithmetic on the stored float32 values, float32 outputs (half the output bytes); PS then differs from
+#     the reference by a few 1e-7 relative and, when the last pass ends within ~0.03 m2/s2 of the threshold, by one pass.
+f32_file_mode = 'reference'

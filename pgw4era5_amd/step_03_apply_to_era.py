@@ -131,15 +131,29 @@ def _upload_era(ctx, era, dtype):
     return out
 
 
+def ref_dtype_mode(dtype, ref_dtype=None):
+    """Whether a file of storage `dtype` runs in reference-dtype mode (settings.f32_file_mode; float32 files only)."""
+    if np.dtype(dtype) != np.float32:
+        if ref_dtype:
+            raise ValueError('reference-dtype mode is the float32-file mode (float64 files already compute as the reference does)')
+        return False
+    if ref_dtype is None:
+        if S.f32_file_mode not in ('reference', 'fast'):
+            raise ValueError("settings.f32_file_mode must be 'reference' or 'fast'")
+        return S.f32_file_mode == 'reference'
+    return bool(ref_dtype)
+
+
 def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, out=None, keep_hur=False):
+                        p_ref=None, out=None, keep_hur=False, ref_dtype=None):
     """The per-file compute path of pgw_for_era5 (reference step_03:62-346, i_reinterp = 0,
     fixed p_ref) on device arrays: ONE call into the C-ABI (`pgw_step03_file`).
 
     era: dict of DeviceArrays PS,FIS,(T_SKIN,FR_LAND,FR_SEA_ICE) (1,nlat,nlon); T,QV,U,V
     (1,N,nlat,nlon); T_SO (1,nsoil,nlat,nlon).  coeffs: dict ak,bk,[akm,bkm],soil1 (host).
     deltas: DeltaSet.  out: optional dict of preallocated output DeviceArrays (reused
-    across files).  Returns (dict of DeviceArrays, info)."""
+    across files).  ref_dtype (float32 storage only; default settings.f32_file_mode): reference-dtype mode, T, QV, U, V
+    come back as float64 arrays like the reference's `era + delta`.  Returns (dict of DeviceArrays, info)."""
     lib, h = ctx.lib, ctx.handle
     if p_ref is None:
         p_ref = S.p_ref_inp
@@ -153,10 +167,12 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
         # the file the reference fails in vert_interp_delta -> interp_logp_4d (functions.py:457-459)
         raise ValueError('Time dimension of input files is inconsistent!')
     out = {} if out is None else out
+    ref = ref_dtype_mode(dt, ref_dtype)
+    dt4 = np.dtype('float64') if ref else dt                        # era (float32) + delta (float64), step_03:170-173
 
-    def buf(name, shape):
-        if name not in out or out[name].shape != tuple(shape):
-            out[name] = ctx.empty(shape, dt)
+    def buf(name, shape, dtype=dt):
+        if name not in out or out[name].shape != tuple(shape) or out[name].dtype != dtype:
+            out[name] = ctx.empty(shape, dtype)
         return out[name]
 
     ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)           # functions.py:224-283
@@ -175,6 +191,7 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
         a.p_ref = float(p_ref)
     a.dtype, a.ntime, a.nlev, a.nplev, a.ncol = dtype_tag(dt), nt, N, len(plev), nlat * nlon
     a.ignore_top = 1 if ignore_top_pressure_error else 0
+    a.ref_dtype = 1 if ref else 0
     a.max_n_iter = int(S.max_n_iter)
     a.adj_factor, a.thresh = float(S.adj_factor), float(S.thresh_phi_ref_max_error)
     a.x_hi, a.x_new = x_hi, x_new
@@ -204,9 +221,9 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
         a.FR_SEA_ICE_out = buf('FR_SEA_ICE', era['FR_SEA_ICE'].shape).ptr
     a.PS_out = buf('PS', PS.shape).ptr
     for k in ('T', 'QV', 'U', 'V'):
-        setattr(a, k + '_out', buf(k, T.shape).ptr)
+        setattr(a, k + '_out', buf(k, T.shape, dt4).ptr)
     if keep_hur:
-        a.hur_pgw_out = buf('_hur_pgw', T.shape).ptr
+        a.hur_pgw_out = buf('_hur_pgw', T.shape, dt4).ptr
     ctx._check(lib.pgw_step03_file(h, C.byref(a)))
     info = dict(n_iter=a.n_iter, max_err=[a.max_err_hist[i] for i in range(min(a.n_iter, 32))],
                 levels_touched=int(a.levels_touched))
@@ -314,7 +331,7 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
 
 
 def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, dtype=None, i_reinterp=False):
+                        p_ref=None, dtype=None, i_reinterp=False, ref_dtype=None):
     """Whole-file path on in-memory host arrays (upload, compute on the GPU, download)."""
     ctx = default_context()
     if dtype is None:
@@ -326,7 +343,8 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     if i_reinterp:
         out, info = process_file_device_reinterp(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref)
     else:
-        out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref, keep_hur=True)
+        out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref, keep_hur=True,
+                                        ref_dtype=ref_dtype)
     res = {k: v.numpy() for k, v in out.items() if not k.startswith('_')}
     res['RELHUM_pgw'] = out['_hur_pgw'].numpy()
     res.update(info)

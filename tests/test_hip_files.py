@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import pgw_oracle as O
+from oracle import pgw_oracle_refdtype as R
 
 pytestmark = pytest.mark.gpu
 
@@ -24,10 +25,9 @@ def files(tmp_path_factory):
 
 
 def _oracle(c):
-    era64 = {k: (np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
-             for k, v in c['era'].items()}
-    d64 = {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()}
-    return O.pgw_for_era5_arrays(era64, d64, c['delta_times'], c['plev'], c['target_dt'], True)
+    """float32 files in the driver's default mode (settings.f32_file_mode = 'reference'): the oracle that follows numpy's
+    promotion through the reference's lines, fed the float32 arrays as they are."""
+    return R.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
 
 
 def test_step03_cli_end_to_end(files):
@@ -42,9 +42,14 @@ def test_step03_cli_end_to_end(files):
         assert n == want['n_iter']
         ds = ncio.open_dataset(os.path.join(out_dir, 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])), decode_times=False)
         assert 'RELHUM' not in ds
-        for name in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
-            np.testing.assert_allclose(ds[name].values, want[name], rtol=3e-6 if name == 'QV' else 1e-6, atol=1e-5 if name in 'UV' else 1e-12,
-                                       equal_nan=True, err_msg=name)
+        for name in ['PS', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+            assert ds[name].values.dtype == np.float32                        # updated in place in the file's dtype
+            np.testing.assert_allclose(ds[name].values, want[name], rtol=1.3e-7, atol=0, equal_nan=True, err_msg=name)
+        for name in ['T', 'U', 'V']:
+            assert ds[name].values.dtype == np.float64                        # era + delta: the reference writes float64
+            np.testing.assert_allclose(ds[name].values, want[name], rtol=1e-9, atol=1e-9, err_msg=name)
+        scale = np.nanmax(np.abs(want['QV']), axis=(2, 3), keepdims=True)
+        assert ds['QV'].values.dtype == np.float64 and np.nanmax(np.abs(ds['QV'].values - want['QV']) / scale) < 6e-7
         np.testing.assert_array_equal(ds['FIS'].values, c['era']['FIS'])      # untouched variables pass through
         np.testing.assert_array_equal(ds['ak'].values, c['era']['ak'])
 

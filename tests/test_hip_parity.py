@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import pgw_oracle as O
+from oracle import pgw_oracle_refdtype as R
 
 pytestmark = pytest.mark.gpu
 
@@ -295,7 +296,9 @@ def test_adjust_ps_loop_not_converged(F):
 def test_whole_file_vs_oracle(dtype):
     from pgw4era5_amd import step_03_apply_to_era as s3
     c = _case(10, 10, 20, seed=0, dtype=dtype)          # BASELINE.json configs[0] shape
-    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    # float32 storage here in the 'fast' mode (float64 arithmetic on the stored values); the reference-dtype mode has
+    # its own tests below (test_reference_dtype_mode_*)
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, ref_dtype=False)
     era64 = {k: (np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
              for k, v in c['era'].items()}
     d64 = {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()}
@@ -501,7 +504,8 @@ def test_local_p_ref_mode_vs_oracle(dtype):
     (reference step_03_apply_to_era.py:219-253, functions.py:583-598)."""
     from pgw4era5_amd import step_03_apply_to_era as s3
     c = _case(9, 14, 30, seed=21, dtype=dtype)
-    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref='local')
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref='local',
+                                 ref_dtype=False)
     f64 = lambda x: np.asarray(x, dtype=np.float64)
     era = {k: (f64(v) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in c['era'].items()}
     d = {k: f64(v) for k, v in c['deltas'].items()}
@@ -519,6 +523,14 @@ def test_local_p_ref_mode_vs_oracle(dtype):
     np.testing.assert_allclose(got['PS'], want['ps_pgw'], rtol=tol)
     np.testing.assert_allclose(got['QV'], want['hus_pgw'], rtol=tol if dtype == np.float64 else 3e-6, atol=1e-18)
     np.testing.assert_allclose(got['max_err'], want['max_err'], rtol=1e-6 if dtype == np.float64 else 1e-5, atol=1e-7)
+    if dtype == np.float32:
+        # reference-dtype mode with the local reference level (float32 delta_ps / ps_pgw / phi): same pass count here,
+        # PS within the float32 noise floor of the fast mode
+        ref = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref='local',
+                                     ref_dtype=True)
+        assert ref['T'].dtype == np.float64 and ref['PS'].dtype == np.float32
+        assert ref['n_iter'] == got['n_iter']
+        np.testing.assert_allclose(ref['PS'], got['PS'], rtol=1.5e-6)
 
 
 def test_local_p_ref_no_candidate_error():
@@ -572,6 +584,117 @@ def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
     assert b['n_iter'] == a['n_iter']
 
 
+# ------------------------------------------------------------------ reference-dtype mode (float32 ERA5 files)
+def _scaled_qv_diff(a, b):
+    """max |a - b| relative to each level's largest value (hur_pgw crosses zero in the dry stratosphere, where a
+    pointwise relative difference says nothing)."""
+    scale = np.nanmax(np.abs(b), axis=(2, 3), keepdims=True)
+    return np.nanmax(np.abs(a - b) / scale)
+
+
+@pytest.mark.parametrize('delta_dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('shape,seed', [((10, 10, 20), 0), ((24, 36, 60), 1), ((7, 13, 21), 2), ((3, 5, 137), 3)])
+def test_reference_dtype_mode_vs_refdtype_oracle(shape, seed, delta_dtype):
+    """float32 ERA5 file in the default mode (settings.f32_file_mode = 'reference', pgw_file_args.ref_dtype = 1) against
+    oracle/pgw_oracle_refdtype.py, which follows numpy's promotion through the reference's lines: float32 phi_hl per level,
+    float32 tav of the ERA state, float32 delta_ps / ps_pgw, float32 e_sat chain of RELHUM; 4-D outputs float64.
+    Same pass count and error history; PS identical up to one float32 ulp; T, U, V to 1e-9; QV to a few float32 ulp of the
+    float32 exp the reference takes (numpy SIMD expf vs device expf) relative to the level's scale."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    nlat, nlon, nlev = shape
+    c = _case(nlat, nlon, nlev, seed=seed, dtype=np.float32)
+    c['deltas'] = {k: v.astype(delta_dtype) for k, v in c['deltas'].items()}
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    # the device holds the deltas in the ERA storage type: the oracle sees the same float32 values
+    d32 = {k: v.astype(np.float32) for k, v in c['deltas'].items()}
+    want = R.pgw_for_era5_arrays(c['era'], d32, c['delta_times'], c['plev'], c['target_dt'], True)
+    assert got['n_iter'] == want['n_iter']
+    np.testing.assert_allclose(got['max_err'], want['max_err'], rtol=0, atol=2e-3)
+    for k in ('T', 'QV', 'U', 'V', 'RELHUM_pgw'):
+        assert got[k].dtype == np.float64 and want[k].dtype == np.float64, k
+    for k in ('PS', 'T_SKIN', 'T_SO', 'FR_SEA_ICE'):
+        assert got[k].dtype == np.float32 and want[k].dtype == np.float32, k
+        np.testing.assert_allclose(got[k], want[k], rtol=1.3e-7, atol=0, equal_nan=True, err_msg=k)
+    for k in ('T', 'U', 'V'):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert _scaled_qv_diff(got['QV'], want['QV']) < 6e-7
+    # the float64-arithmetic mode on the same file is measurably further away (that is why this mode exists)
+    fast = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, ref_dtype=False)
+    assert fast['T'].dtype == np.float32
+    d_ref = np.max(np.abs(got['PS'].astype(np.float64) - want['PS']) / want['PS'])
+    d_fast = np.max(np.abs(fast['PS'].astype(np.float64) - want['PS']) / want['PS'])
+    assert d_ref <= 1.3e-7 and d_ref <= d_fast
+
+
+def test_reference_dtype_mode_exact_record_and_errors():
+    """A time stamp that is a delta record (no time interpolation: the deltas stay float32, functions.py:282-283, and numba
+    takes y_hi - y_lo in float32, :575-578) and the data errors of the file path, in reference-dtype mode."""
+    import datetime as dt
+    from pgw4era5_amd import step_03_apply_to_era as s3, synthetic
+    c = synthetic.make_case(6, 10, 40, seed=61, dtype=np.float32, target_dt=dt.datetime(2006, 3, 15, 12))
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    want = R.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    assert got['n_iter'] == want['n_iter']
+    np.testing.assert_allclose(got['PS'], want['PS'], rtol=1.3e-7)
+    for k in ('T', 'U', 'V'):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert _scaled_qv_diff(got['QV'], want['QV']) < 6e-7
+    with pytest.raises(ValueError) as e:
+        s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], False)
+    assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
+    with pytest.raises(ValueError) as e:
+        s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref=100000.0)
+    assert 'p_ref locally lies below the surface' in str(e.value)
+    with pytest.raises(ValueError):                  # float64 storage has no reference-dtype mode
+        c64 = _case(4, 5, 12, seed=5)
+        s3.pgw_for_era5_arrays(c64['era'], c64['deltas'], c64['delta_times'], c64['plev'], c64['target_dt'], True, ref_dtype=True)
+
+
+@pytest.mark.parametrize('shape,seed,label', [((10, 10, 20), 0, 'config 1 (10x10 L20)'),
+                                              ((104, 1440, 137), 1, '104-row band of config 2 (0.25 deg L137)')])
+def test_float32_file_three_way_record(shape, seed, label):
+    """on float32 files, record the pass count and max |dPS| of (a) the reference-dtype oracle = what the
+    reference's numpy promotion computes, (b) the float64 oracle on the same values, (c) the HIP float32-storage path in
+    both modes.  The numbers go to gpurun_out/f32_three_way.json (DESIGN.md section 2 quotes them)."""
+    import json
+    import os
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    nlat, nlon, nlev = shape
+    c = _case(nlat, nlon, nlev, seed=seed, dtype=np.float32)
+    args = (c['delta_times'], c['plev'], c['target_dt'], True)
+    ref = R.pgw_for_era5_arrays(c['era'], c['deltas'], *args)
+    era64 = {k: (np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
+             for k, v in c['era'].items()}
+    f64 = O.pgw_for_era5_arrays(era64, {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()}, *args)
+    hip_ref = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ref_dtype=True)
+    hip_fast = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ref_dtype=False)
+    ps_ref = ref['PS'].astype(np.float64)
+
+    def row(name, r):
+        return dict(path=name, n_iter=int(r['n_iter']), max_err=[float(x) for x in r['max_err']],
+                    max_abs_dPS_vs_reference_dtype=float(np.max(np.abs(np.asarray(r['PS'], dtype=np.float64) - ps_ref))),
+                    max_rel_dPS_vs_reference_dtype=float(np.max(np.abs(np.asarray(r['PS'], dtype=np.float64) - ps_ref) / ps_ref)))
+    rows = [row('oracle reference-dtype (numpy promotion of the reference)', ref), row('oracle float64', f64),
+            row('HIP float32 storage, reference-dtype mode', hip_ref), row('HIP float32 storage, float64 arithmetic (fast)', hip_fast)]
+    print('\n' + label)
+    for r in rows:
+        print('  %-58s n_iter %d  last max|err| %.4f  max|dPS| %.3e Pa (%.2e rel)'
+              % (r['path'], r['n_iter'], r['max_err'][-1], r['max_abs_dPS_vs_reference_dtype'], r['max_rel_dPS_vs_reference_dtype']))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out_dir):
+        path = os.path.join(out_dir, 'f32_three_way.json')
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec[label] = rows
+        json.dump(rec, open(path, 'w'), indent=1)
+    # the reference-dtype mode reproduces the reference's float32 flow: same pass count, PS within one float32 ulp
+    assert hip_ref['n_iter'] == ref['n_iter']
+    assert rows[2]['max_rel_dPS_vs_reference_dtype'] <= 1.3e-7
+    np.testing.assert_allclose(hip_ref['max_err'], ref['max_err'], rtol=0, atol=2e-3)
+    # float64 arithmetic (oracle and HIP alike) sits a float32-phi noise floor away from it
+    assert hip_fast['n_iter'] == f64['n_iter']
+    assert rows[3]['max_rel_dPS_vs_reference_dtype'] < 1.5e-6
+
+
 # ------------------------------------------------------------------ ragged / odd shapes, other level sets
 @pytest.mark.parametrize('shape', [(7, 13, 21), (3, 5, 9), (1, 3, 6), (2, 2, 5)])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
@@ -581,7 +704,7 @@ def test_whole_file_odd_shapes(shape, dtype):
     from pgw4era5_amd import step_03_apply_to_era as s3
     nlat, nlon, nlev = shape
     c = _case(nlat, nlon, nlev, seed=50 + nlat * nlon, dtype=dtype)
-    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, ref_dtype=False)
     era64 = {k: (np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v)
              for k, v in c['era'].items()}
     want = O.pgw_for_era5_arrays(era64, {k: np.asarray(v, dtype=np.float64) for k, v in c['deltas'].items()},
@@ -644,10 +767,10 @@ def test_kernel_variants_are_bit_identical(opts, dtype):
     from pgw4era5_amd.device import default_context
     ctx = default_context()
     c = _case(8, 12, 27, seed=81, dtype=dtype)
-    a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    a = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, ref_dtype=False)
     old = {k: ctx.set_option(k, v) for k, v in opts.items()}
     try:
-        b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+        b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, ref_dtype=False)
     finally:
         for k, v in old.items():
             ctx.set_option(k, v)
