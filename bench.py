@@ -14,12 +14,21 @@ timing).
     python bench.py [--gpus N] [--steps K] [--warmup W] [--storage f64|f32]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU; it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...`
+as a CHILD process, relays the child's JSON line and exits with its code (reference `-p N`,
+parallel.py:18-32 / step_03_apply_to_era.py:630-638).  Every rank asserts WORLD_SIZE == --gpus.
+
 Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant
-kernel, HIP-event timed inside this run) and `cpu_baseline` (the numpy oracle, rank 0, N = 1
-only, on a bounded latitude band of the same file).
+kernel, HIP-event timed inside this run, beside the figure recomputed from the committed rocprofv3
+summary), `cpu_baseline` (the numpy oracle on the host cores, rank 0, N = 1 only: one process and
+file-parallel processes, on bounded latitude bands of the same file) and, at N = 1, `extras`
+(PCIe-inclusive rate, end-to-end rate through the command line incl. NetCDF I/O, step_02 regridding of
+BASELINE.json configs[3], float32-storage rates) - reported, never `value`.
 """
 import argparse
 import datetime as dt
+import datetime as dt_mod
 import json
 import os
 import sys
@@ -32,36 +41,79 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=10)
     p.add_argument('--warmup', type=int, default=2)
     p.add_argument('--storage', choices=['f64', 'f32'], default='f64')
+    p.add_argument('--f32-mode', choices=['reference', 'fast'], default='reference',
+                   help="--storage f32 only: reference-dtype mode (float64 4-D outputs) or float64 arithmetic with float32 outputs")
     p.add_argument('--nlat', type=int, default=721)
     p.add_argument('--nlon', type=int, default=1440)
     p.add_argument('--nlev', type=int, default=137)
-    p.add_argument('--cpu-rows', type=int, default=160, help='latitude rows of the CPU-baseline sample')
+    p.add_argument('--cpu-rows', type=int, default=160, help='latitude rows of the one-process CPU-baseline sample')
+    p.add_argument('--cpu-procs', type=int, default=0,
+                   help='processes of the file-parallel CPU-baseline leg (0: min(host cores, 16), the CPU share of a 1-GPU box)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--overlap-streams', type=int, default=2,
                    help='extra (untimed-for-value) region with this many files in flight per GPU on separate HIP streams; 0 = skip')
-    p.add_argument('--extras', action='store_true',
-                   help='also time (outside the timed region) the step_02 regridding of BASELINE.json configs[3] and the '
-                        'PCIe-inclusive per-file rate (pinned host buffers -> H2D -> path -> D2H)')
+    p.add_argument('--no-extras', action='store_true',
+                   help='skip the N = 1 side measurements (PCIe-inclusive rate, end-to-end command line, step_02 regridding, '
+                        'float32 storage)')
+    p.add_argument('--extras', action='store_true', help='(default at N = 1; kept for older command lines)')
+    p.add_argument('--e2e-files', type=int, default=4, help='files of the end-to-end command-line measurement (0 = skip)')
+    p.add_argument('--e2e-dir', default=None, help='scratch directory for the end-to-end files (default: a temp dir)')
     p.add_argument('--full-column', action='store_true',
                    help='pass kernel reads every level (input-independent traffic) instead of stopping above p_ref')
-    return p.parse_args()
+    p.add_argument('--dry-run', action='store_true',
+                   help='no GPU work: ranks rendezvous, count each other and print the line with value null '
+                        '(CPU rehearsal of the multi-rank launch path; use with PGW_BENCH_BACKEND=gloo)')
+    return p.parse_args(argv)
+
+
+def spawn_ranks(a, argv):
+    """`--gpus N` given to a plain process: start N ranks as a child `torch.distributed.run` (never exec: this
+    process may be watched by a profiler that has already initialised the GPU) and relay its line and exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+    if r.stderr:
+        sys.stderr.write(r.stderr[-8000:])
+    if line is None:
+        sys.stderr.write('bench.py: the %d-rank child printed no result line (exit code %d)\n%s\n'
+                         % (a.gpus, r.returncode, r.stdout[-2000:]))
+        return r.returncode or 1
+    d = json.loads(line)
+    if d.get('n_gpus') != a.gpus:
+        sys.stderr.write('bench.py: asked for %d ranks, the line reports %r\n' % (a.gpus, d.get('n_gpus')))
+        return 1
+    print(line, flush=True)
+    return r.returncode
 
 
 def kernel_bytes(name, N, S, ncol, s, info):
-    """Algorithmic bytes one launch of kernel `name` moves."""
+    """Algorithmic bytes one launch of kernel `name` moves.  s = storage bytes of the ERA5 fields
+    and delta records, info['so'] = bytes of the PGW level arrays (T_pgw, e, QV, U, V out: 8 in reference-dtype mode)."""
+    so = info.get('so', s)
     if name == 'integ_geopot':        # pa_hl, ta, hus, zgs in; phi_ref out          (3N+3) ncol
         return (3 * N + 3) * ncol * s
-    if name == 'adjust_ps_step':      # ta, e per level read; PS,FIS (storage) + 6 fp64 state words
+    if name == 'adjust_ps_step':      # ta_pgw, e per level read; PS,FIS (storage) + 6 fp64 state words
         lv = info.get('levels_per_launch', N * ncol)
-        return 2 * lv * s + ncol * (2 * s + 6 * 8)
+        return 2 * lv * so + ncol * (2 * s + 6 * 8)
     if name == 'quad_delta':          # T, QV, U, V in; T_pgw, e, U_pgw, V_pgw out; 2 records x S for 4 variables; 8 2-D fields
-        return (8 * N + 8 * S + 8) * ncol * s
+        return (4 * N * s + 4 * N * so + (8 * S + 8) * s) * ncol
     if name == 'thermo_delta':        # T, QV in; T_pgw, e out; 2 records x S for ta and hur; 7 2-D fields
         return (4 * N + 4 * S + 7) * ncol * s
     if name == 'wind_delta':          # U, V in; U_pgw, V_pgw out; 2 records x S for ua and va; PS
@@ -76,46 +128,92 @@ def kernel_bytes(name, N, S, ncol, s, info):
     if name == 'rh_to_q':             # hur, ta in, e out (vapour pressure pre-pass)
         return 3 * N * ncol * s
     if name == 'finalize':            # e in, QV out (levels the quad kernel has not finalised already), PS in/out, delta_ps
-        return 2 * (N - info.get('qv_done_levels', 0)) * ncol * s + ncol * (2 * s + 8)
+        return 2 * (N - info.get('qv_done_levels', 0)) * ncol * so + ncol * (2 * s + 8)
     if name == 'pressure':            # ps in, pa_hl out
         return (N + 2) * ncol * s
     return 0
 
 
-def main():
-    a = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(a, argv)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE is %d: start it as `python bench.py --gpus N` or as '
+                         '`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`\n' % (a.gpus, world))
+        return 2
     dist = None
+    backend = None
     if world > 1:
         # torch first: libpgw_hip.so then binds to the HIP runtime torch loaded (pgw4era5_amd/_lib.py)
         import torch
         import torch.distributed as dist
         # 'nccl' IS RCCL on ROCm.  PGW_BENCH_BACKEND=gloo only exists to rehearse the multi-rank code path
-        # on a box with fewer GPUs than ranks (ranks then share devices: local % device_count).
+        # on a box with fewer GPUs than ranks (ranks then share devices: local % device_count) or without one (--dry-run).
         backend = os.environ.get('PGW_BENCH_BACKEND', 'nccl')
-        ndev = max(torch.cuda.device_count(), 1)
-        local = local % ndev
-        torch.cuda.set_device(local)
         if backend == 'nccl':
+            ndev = max(torch.cuda.device_count(), 1)
+            local = local % ndev
+            torch.cuda.set_device(local)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)
+            if not a.dry_run:
+                local = local % max(torch.cuda.device_count(), 1)
+
+    def reduce(x, op):
+        """float all-reduce over the ranks (RCCL on device memory, gloo on host memory)"""
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return float(t.item())
+
+    if a.dry_run:
+        if dist is not None:
+            dist.barrier()
+        seen = int(round(reduce(1.0, 'SUM')))
+        el = reduce(1e-3 * (rank + 1), 'MAX')
+        if rank == 0:
+            print(json.dumps({'metric': 'ERA5 files/hour (0.25deg L137), step_03 hot path, inputs resident in HBM',
+                              'value': None, 'unit': 'files/hour', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+                              'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                              'dtype': 'f64', 'data': 'synthetic', 'dry_run': True,
+                              'collective': {'backend': backend, 'ranks_counted_by_all_reduce': seen, 'max_reduced': el},
+                              'config': {'workload': 'dry run: launch path only, no GPU work'}}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
     import numpy as np
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
     from pgw4era5_amd.device import Context
 
     dtype = np.float64 if a.storage == 'f64' else np.float32
+    ref = (a.storage == 'f32' and a.f32_mode == 'reference')
     s = np.dtype(dtype).itemsize
+    so = 8 if (ref or a.storage == 'f64') else 4         # bytes per element of the PGW level arrays (T_pgw, e, QV, U, V out)
+    t0 = time.time()
+    case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1 + rank, dtype=dtype)
+    t_gen = time.time() - t0
+    # CPU baseline first: this process has not touched the GPU yet, so the file-parallel leg can fork its workers
+    cpu = None
+    if not a.no_cpu_baseline and world == 1 and rank == 0:
+        try:
+            cpu = cpu_baseline(case, a, np)
+        except Exception as e:                      # noqa: BLE001 - reported in the line, the GPU measurement goes on
+            cpu = {'error': '%s: %s' % (type(e).__name__, e)}
     ctx = Context(local)
     if a.full_column:
         ctx.set_option('full_column', 1)
     from pgw4era5_amd import device as _device
     _device._default = ctx                 # the functions.py mirror uses the process-wide context
-    t0 = time.time()
-    case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1 + rank, dtype=dtype)
-    t_gen = time.time() - t0
     ncol = a.nlat * a.nlon
     N, S = a.nlev, len(case['plev'])
     deltas = s3.DeltaSet(ctx, case['deltas'], case['delta_times'], case['plev'], dtype)
@@ -129,35 +227,34 @@ def main():
         ctx.sync()
         if dist is not None:
             dist.barrier()
-            import torch
-            torch.cuda.synchronize()
+            if backend == 'nccl':
+                import torch
+                torch.cuda.synchronize()
 
     infos = []
     if not os.environ.get('PGW_BENCH_NOPROF'):      # A/B knob: cost of the per-launch HIP events
         ctx.profile(True)                           # on during warm-up too, so the event pool is populated
     for i in range(a.warmup):
-        _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[i], True, out=out)
+        _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[i], True, out=out, ref_dtype=ref)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[a.warmup + i], True, out=out)
+        _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[a.warmup + i], True, out=out, ref_dtype=ref)
         infos.append(info)
     barrier()
     elapsed = time.perf_counter() - t0
     prof = {k: ctx.profile_get(k) for k in ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'finalize',
                                             'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q',
                                             'pressure', 'time_lerp')}
-    micro = microbench(ctx, era, coeffs, a, np) if (rank == 0 and world == 1) else {}       # N = 1 only: keeps multi-rank runs short
-    overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a) \
-        if (rank == 0 and world == 1 and a.overlap_streams > 1) else None
+    solo = (rank == 0 and world == 1)
+    micro = microbench(ctx, era, coeffs, a, np) if solo else {}       # N = 1 only: keeps multi-rank runs short
+    overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a, ref) if (solo and a.overlap_streams > 1) else None
     ctx.profile(False)
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = reduce(elapsed, 'MAX')
+    ranks_seen = int(round(reduce(1.0, 'SUM')))
+    iters_min = int(round(reduce(float(min(i['n_iter'] for i in infos)), 'MIN')))
+    iters_max = int(round(reduce(float(max(i['n_iter'] for i in infos)), 'MAX')))
 
     if rank == 0:
         n_iter = [i['n_iter'] for i in infos]
@@ -169,7 +266,7 @@ def main():
             n_pure += 1
         # pure-pressure levels: their final QV is written by k_delta_quad (stop-above-p_ref passes)
         quad = not a.full_column and ctx.get_option('quad') != 0
-        kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0)
+        kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0, so=so)
         kern = {}
         for k, (cnt, ms) in prof.items():
             if cnt == 0:
@@ -181,13 +278,16 @@ def main():
         cand = [k for k in kern if kern[k]['GBps']]
         if not cand:                       # PGW_BENCH_NOPROF: no per-kernel timings
             print(json.dumps({'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'note': 'launch profiling disabled'}), flush=True)
-            return
+            return 0
         dom = max(cand, key=lambda k: kern[k]['total_ms'])
         traffic, tsrc = pmc_traffic(dom, a)
         roof = dict(bound='hbm', kernel=dom, achieved=kern[dom]['GBps'], peak=HBM_PEAK_GBS, unit='GB/s',
                     frac=round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_unit='GB/launch',
                     traffic_source=tsrc, avg_launch_ms=kern[dom]['avg_ms'],
-                    algorithmic_GB_per_launch=kern[dom]['algo_GB'])
+                    algorithmic_GB_per_launch=kern[dom]['algo_GB'],
+                    timing='HIP events on the launching stream, this run (frac); frac_rocprof = the same algorithmic bytes over '
+                           'the committed rocprofv3 --kernel-trace average of the timed launches')
+        roof.update(rocprof_frac(dom, a, kern[dom]['algo_GB']))
         valu = pmc_valu(dom, a, kern[dom]['avg_ms'])
         if valu:
             roof['valu_fp64'] = valu
@@ -201,27 +301,39 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'Single ERA5 file, global 0.25deg (%dx%d) L%d, plev%d monthly deltas, per MI355X'
                                    % (a.nlon, a.nlat, a.nlev, S),
-                       'storage': a.storage, 'files_per_rank': a.steps, 'sharding': 'one file per rank per step',
+                       'storage': a.storage if a.storage == 'f64' else 'f32 (%s mode)' % a.f32_mode,
+                       'files_per_rank': a.steps, 'sharding': 'file i -> rank i mod W, no data-path collective',
                        'iterations_per_file': n_iter[0] if len(set(n_iter)) == 1 else n_iter,
+                       'iterations_per_file_over_ranks': [iters_min, iters_max],
                        'pass_kernel': 'full_column' if a.full_column else 'stops_above_p_ref',
                        'mean_levels_read_per_column_per_pass': round(lv_per_launch / ncol, 2)},
+            'collective': {'backend': ('rccl (torch nccl)' if backend == 'nccl' else backend) if world > 1 else None,
+                           'ranks_counted_by_all_reduce': ranks_seen,
+                           'use': 'barrier + MAX of the elapsed time; files are independent'},
             'roofline': roof,
             'kernels': kern,
             'signature_kernels': micro,
-            'extras': extras(ctx, case, era, coeffs, deltas, a, np) if (a.extras and world == 1) else None,
+            'extras': None,
             'overlap': overlap,
             'device': ctx.device_name(),
             'setup_s': round(t_gen, 1),
         }
-        if not a.no_cpu_baseline and world == 1:
-            res['cpu_baseline'] = cpu_baseline(case, a, np)
+        if solo and not a.no_extras:
+            try:
+                res['extras'] = extras(ctx, case, era, coeffs, deltas, a, np)
+            except Exception as e:          # noqa: BLE001 - side measurements never cost the headline line
+                res['extras'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if cpu is not None:
+            res['cpu_baseline'] = cpu
+        assert res['n_gpus'] == a.gpus == ranks_seen, (res['n_gpus'], a.gpus, ranks_seen)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def overlap_region(device, era, coeffs, deltas, stamps, a):
+def overlap_region(device, era, coeffs, deltas, stamps, a, ref=False):
     """Same K files, but `--overlap-streams` files in flight per GPU: one host thread + one
     pgw_ctx (HIP stream, workspaces, outputs) per in-flight file, so the fp64-VALU-bound delta
     kernels of one file overlap the HBM-bound loop / finalize kernels of another and the host-side
@@ -240,14 +352,14 @@ def overlap_region(device, era, coeffs, deltas, stamps, a):
         d.ctx = c
         dsets.append(d)
     for i, c in enumerate(ctxs):       # warm-up: workspaces + level tables of every context
-        s3.process_file_device(c, era, coeffs, dsets[i], stamps[0], True, out=outs[i])
+        s3.process_file_device(c, era, coeffs, dsets[i], stamps[0], True, out=outs[i], ref_dtype=ref)
         c.sync()
     errs = []
 
     def work(i):
         try:
             for k in range(i, len(stamps), n):
-                s3.process_file_device(ctxs[i], era, coeffs, dsets[i], stamps[k], True, out=outs[i])
+                s3.process_file_device(ctxs[i], era, coeffs, dsets[i], stamps[k], True, out=outs[i], ref_dtype=ref)
             ctxs[i].sync()
         except Exception as e:        # noqa: BLE001
             errs.append(repr(e))
@@ -335,16 +447,17 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
     for k, p in zip(names, hp):
         C.memmove(p, case['era'][k].ctypes.data, n4)
     res = {}
-    s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=res)
+    ref = (a.storage == 'f32' and a.f32_mode == 'reference')
+    s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=res, ref_dtype=ref)
     ctx.sync()
     t0 = time.perf_counter()
     reps = 2
     for _ in range(reps):
         for k, p in zip(names, hp):
             ctx._check(ctx.lib.pgw_memcpy_h2d(ctx.handle, era[k].ptr, p, n4))
-        s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=res)
+        s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=res, ref_dtype=ref)
         for k, p in zip(names, hp):
-            ctx._check(ctx.lib.pgw_memcpy_d2h(ctx.handle, p, res[k].ptr, n4))
+            ctx._check(ctx.lib.pgw_memcpy_d2h(ctx.handle, p, res[k].ptr, n4))      # n4 bytes of each output (all of it unless ref)
         ctx.sync()
     el = (time.perf_counter() - t0) / reps
     for p in hp:
@@ -352,7 +465,64 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
     out['pcie_inclusive'] = dict(ms_per_file=round(el * 1e3, 2), files_per_hour=round(3600.0 / el, 1),
                                  GB_moved_each_way=round(4 * n4 / 1e9, 3),
                                  note='pinned H2D of T,QV,U,V + path + D2H of T,QV,U,V on one stream')
+    for v in res.values():
+        v.free()
+    # float32 storage (what real ERA5 files hold), HBM-resident like `value`: both modes of settings.f32_file_mode
+    if dt == np.float64:
+        try:
+            out['f32_storage'] = f32_storage(ctx, case, coeffs, a, np)
+        except Exception as e:      # noqa: BLE001
+            out['f32_storage'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if a.e2e_files > 0:
+        try:
+            out['end_to_end_cli'] = end_to_end(a)
+        except Exception as e:      # noqa: BLE001
+            out['end_to_end_cli'] = {'error': '%s: %s' % (type(e).__name__, e)}
     return out
+
+
+def f32_storage(ctx, case, coeffs, a, np, steps=5):
+    """The timed region again on a float32 copy of the same file: reference-dtype mode (float64 4-D outputs, the
+    reference's roundings) and float64 arithmetic with float32 outputs."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    f32 = np.float32
+    era32 = {k: (v.astype(f32) if isinstance(v, np.ndarray) and v.ndim >= 3 else v) for k, v in case['era'].items()}
+    d32 = {k: v.astype(f32) for k, v in case['deltas'].items()}
+    deltas = s3.DeltaSet(ctx, d32, case['delta_times'], case['plev'], f32)
+    era = s3._upload_era(ctx, era32, f32)
+    del era32, d32
+    res = {}
+    for mode, ref in (('reference', True), ('fast', False)):
+        outb = {}
+        s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=outb, ref_dtype=ref)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            _, info = s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'] + dt_mod.timedelta(hours=i), True,
+                                             out=outb, ref_dtype=ref)
+        ctx.sync()
+        el = (time.perf_counter() - t0) / steps
+        res[mode] = dict(ms_per_file=round(el * 1e3, 3), files_per_hour=round(3600.0 / el, 1), iterations=info['n_iter'])
+        for v in outb.values():
+            v.free()
+    for v in list(era.values()) + list(deltas.dev.values()) + [deltas.ts_clim]:
+        v.free()
+    return res
+
+
+def end_to_end(a):
+    """tools/e2e_cli.py in a child process: K float32 files through the step_03 command line INCLUDING NetCDF-3 read /
+    write (settings.f32_file_mode default: float64 T, QV, U, V out like the reference)."""
+    import subprocess
+    import tempfile
+    d = a.e2e_dir or tempfile.mkdtemp(prefix='pgw_e2e_')
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'e2e_cli.py'), '--files', str(a.e2e_files), '--nlat', str(a.nlat),
+           '--nlon', str(a.nlon), '--nlev', str(a.nlev), '--dir', d]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith('{'):
+            return json.loads(ln)
+    raise RuntimeError('e2e_cli.py failed (%d): %s' % (r.returncode, r.stderr[-400:]))
 
 
 def microbench(ctx, era, coeffs, a, np, reps=5):
@@ -412,6 +582,30 @@ PMC_KERNEL = {'integ_geopot': 'k_integ_geopot', 'adjust_ps_step': 'k_adjust_ps_s
               'phi_ref_hybrid': 'k_phi_ref_hybrid', 'quad_delta': 'k_delta_quad'}
 
 
+def _profile_tag(a):
+    return a.storage if a.storage == 'f64' else ('f32' if a.f32_mode == 'fast' else 'f32ref')
+
+
+def rocprof_frac(kernel, a, algo_GB):
+    """The roofline fraction recomputed from the committed rocprofv3 --kernel-trace summary of this same command
+    (profiles/kernel_stats_<tag>_<storage>.csv, written by profiles/summarize.py from the per-dispatch trace with the
+    warm-up launches dropped): algorithmic bytes / average duration of the TIMED launches / 8 TB/s."""
+    import csv
+    import glob
+    if (a.nlat, a.nlon, a.nlev) != (721, 1440, 137):
+        return {}
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'kernel_stats_*_%s.csv' % _profile_tag(a))))
+    if not files:
+        return {}
+    pat = PMC_KERNEL.get(kernel, '?')
+    for r in csv.DictReader(open(files[-1])):
+        if r['kernel'].startswith(pat) and 'timed_avg_us' in r and r['timed_avg_us']:
+            avg = float(r['timed_avg_us'])
+            return {'frac_rocprof': round(algo_GB / (avg / 1e6) / HBM_PEAK_GBS, 4), 'rocprof_timed_avg_launch_ms': round(avg / 1e3, 4),
+                    'rocprof_timed_launches': int(r['timed_calls']), 'rocprof_source': os.path.relpath(files[-1], ROOT)}
+    return {}
+
+
 def pmc_traffic(kernel, a):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
     (profiles/pmc_summary_*.json, produced by profiles/summarize.py from separate FETCH_SIZE /
@@ -421,7 +615,7 @@ def pmc_traffic(kernel, a):
     import glob
     if (a.nlat, a.nlon, a.nlev) != (721, 1440, 137):
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_summary_*_%s.json' % a.storage)))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_summary_*_%s.json' % _profile_tag(a))))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -447,7 +641,7 @@ def pmc_valu(kernel, a, avg_ms):
     import glob
     if (a.nlat, a.nlon, a.nlev) != (721, 1440, 137):
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_summary_*_%s.json' % a.storage)))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'pmc_summary_*_%s.json' % _profile_tag(a))))
     if not files:
         return None
     d = json.load(open(files[-1]))
@@ -466,31 +660,71 @@ def pmc_valu(kernel, a, avg_ms):
     return None
 
 
-def cpu_baseline(case, a, np):
-    """The numpy oracle (a port: the reference's xarray/numba stack is not installable here) on
-    a latitude band of the same synthetic file, one host thread, scaled to files/hour."""
-    from oracle import pgw_oracle as O
-    rows = min(a.cpu_rows, a.nlat)
-    j0 = max((a.nlat - rows) // 2, 0)
+_CPU_CASE = None          # the synthetic case, inherited by the forked workers of the file-parallel CPU leg
+
+
+def _band(case, np, j0, rows):
     sl = slice(j0, j0 + rows)
     f64 = np.float64
     era = {}
     for k, v in case['era'].items():
-        if isinstance(v, np.ndarray) and v.ndim >= 3:
-            era[k] = np.ascontiguousarray(v[..., sl, :], dtype=f64)
-        else:
-            era[k] = v
+        era[k] = np.ascontiguousarray(v[..., sl, :], dtype=f64) if (isinstance(v, np.ndarray) and v.ndim >= 3) else v
     deltas = {k: np.ascontiguousarray(v[..., sl, :], dtype=f64) for k, v in case['deltas'].items()}
+    return era, deltas
+
+
+def _cpu_worker(args):
+    """One worker of the file-parallel leg: the oracle on its own latitude band (reference: one file per pool worker,
+    parallel.py:20-27); returns (seconds, passes)."""
+    import numpy as np
+    from oracle import pgw_oracle as O
+    j0, rows = args
+    case = _CPU_CASE
+    era, deltas = _band(case, np, j0, rows)
+    t0 = time.perf_counter()
+    out = O.pgw_for_era5_arrays(era, deltas, case['delta_times'], case['plev'], case['target_dt'], ignore_top_pressure_error=True)
+    return time.perf_counter() - t0, out['n_iter']
+
+
+def cpu_baseline(case, a, np):
+    """The numpy oracle (a port: the reference's xarray/numba stack is not installable here) on latitude bands of the
+    same synthetic file, scaled to files/hour: (1) one process = the reference's default `-p 1`
+    (step_03_apply_to_era.py:542), `value`; (2) `procs` processes at once, each on its own band = the reference's
+    file-parallel `-p N` (parallel.py:20-27), `parallel`.  Fully vectorised numpy over the band, not the reference's
+    per-column numba / np.vectorize loops (those cannot run here), so it flatters the CPU side."""
+    global _CPU_CASE
+    import multiprocessing as mp
+    from oracle import pgw_oracle as O
+    rows = min(a.cpu_rows, a.nlat)
+    j0 = max((a.nlat - rows) // 2, 0)
+    era, deltas = _band(case, np, j0, rows)
     t0 = time.perf_counter()
     out = O.pgw_for_era5_arrays(era, deltas, case['delta_times'], case['plev'], case['target_dt'],
                                 ignore_top_pressure_error=True)
     t = time.perf_counter() - t0
     frac = rows / a.nlat
-    return {'value': round(3600.0 / (t / frac), 3), 'unit': 'files/hour', 'cores': 1, 'kind': 'port',
-            'sample': '%d of %d latitude rows (%d columns) of the same file through oracle/pgw_oracle.py '
-                      '(numpy fp64), %.1f s, %d iterations; host has %d cores'
-                      % (rows, a.nlat, rows * a.nlon, t, out['n_iter'], os.cpu_count())}
+    res = {'value': round(3600.0 / (t / frac), 3), 'unit': 'files/hour', 'cores': 1, 'kind': 'port',
+           'sample': '%d of %d latitude rows (%d columns) of the same file through oracle/pgw_oracle.py '
+                     '(numpy fp64), %.1f s, %d iterations; host has %d cores'
+                     % (rows, a.nlat, rows * a.nlon, t, out['n_iter'], os.cpu_count())}
+    del era, deltas, out
+    procs = a.cpu_procs or min(os.cpu_count() or 1, 16)
+    if procs > 1:
+        prow = max(min(a.nlat // procs, 40), 1)            # ~4 s of work per process; 16 bands of 40 rows = 640 of 721 rows
+        _CPU_CASE = case
+        bands = [(i * prow, prow) for i in range(procs)]
+        t0 = time.perf_counter()
+        with mp.get_context('fork').Pool(procs) as pool:   # fork: the workers share the case copy-on-write (no GPU state yet)
+            times = pool.map(_cpu_worker, bands, chunksize=1)
+        wall = time.perf_counter() - t0
+        _CPU_CASE = None
+        files_done = procs * prow / a.nlat
+        res['parallel'] = {'value': round(files_done / wall * 3600.0, 3), 'unit': 'files/hour', 'cores': procs,
+                           'sample': '%d processes at once, %d latitude rows each (%.2f of a file in all), %.1f s wall '
+                                     '(slowest worker %.1f s); host has %d cores'
+                                     % (procs, prow, files_done, wall, max(x[0] for x in times), os.cpu_count())}
+    return res
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -157,6 +157,7 @@ class IterMP:
 
     # self-spawned workers (plain `python step_03... -p N`)
     def _run_spawn(self, func, tasks, world):
+        import queue as _queue
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
         procs = [ctx.Process(target=_worker, args=(r, world, func, tasks, q)) for r in range(world)]
@@ -164,14 +165,40 @@ class IterMP:
             p.start()
         out = [None] * len(tasks)
         errs = []
-        for _ in procs:
-            rank, part, err = q.get()
+        pending = set(range(world))
+        # A worker that dies without posting (a fault or abort inside the HIP library, an OOM kill, a result the queue's
+        # feeder thread cannot pickle) must not leave this process waiting forever: poll the queue and the workers' exit
+        # codes; a worker that has exited gets a short grace period for a message still in the pipe.
+        dead_since = {}
+        grace = float(os.environ.get('PGW_WORKER_GRACE_S', '5'))
+        import time as _time
+        while pending:
+            try:
+                rank, part, err = q.get(timeout=0.2)
+            except _queue.Empty:
+                now = _time.time()
+                for r in list(pending):
+                    if procs[r].exitcode is not None:
+                        dead_since.setdefault(r, now)
+                        if now - dead_since[r] > grace:
+                            pending.discard(r)
+                            errs.append('rank %d: worker process exited with code %s without delivering its results'
+                                        % (r, procs[r].exitcode))
+                if errs and pending:              # one rank is lost: stop the others, the run has failed
+                    for r in pending:
+                        if procs[r].is_alive():
+                            procs[r].terminate()
+                    break
+                continue
+            pending.discard(rank)
             if err:
                 errs.append('rank %d: %s' % (rank, err))
             for i, r in part:
                 out[i] = r
         for p in procs:
-            p.join()
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
         if errs:
             raise RuntimeError('worker failed: ' + '; '.join(errs))
         return out

@@ -3,6 +3,16 @@
 in profiles/.
 
     python profiles/summarize.py <round-tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir> [<pmc_sq_dir>]]
+    python profiles/summarize.py trace <round-tag> <trace_dir> <warmup W> <steps K>
+
+`trace` (round 2 on): kernel_stats_<tag>.csv from the per-dispatch kernel trace of
+    rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py --steps K --warmup W
+        --no-cpu-baseline --overlap-streams 0 --no-extras
+with the warm-up launches dropped: per kernel the dispatches are ordered by start time; a kernel launched c times per
+step (calls = (W + K) * c) loses its first W * c dispatches, any other kernel (the signature micro-benchmarks: one
+warm-up launch + reps) its first one.  Columns: all launches (calls, avg_us, min_us, max_us) as rocprofv3 --stats gives
+them, and timed_calls, timed_avg_us, timed_median_us, timed_min_us, timed_max_us of the timed launches - bench.py's
+`roofline.frac_rocprof` divides the algorithmic bytes by timed_avg_us.
 
 stats_dir: output of  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 bench.py ...
 pmc dirs : output of  rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d <dir> -- python3 bench.py ...
@@ -28,7 +38,33 @@ def short(name):
     return name.replace('pgw::', '')
 
 
+def trace_stats():
+    import statistics
+    tag, d, W, K = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    here = os.path.dirname(os.path.abspath(__file__))
+    f = glob.glob(os.path.join(d, '**', '*_kernel_trace.csv'), recursive=True)[0]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        per[short(r['Kernel_Name'])].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+    with open(os.path.join(here, 'kernel_stats_%s.csv' % tag), 'w') as o:
+        o.write('kernel,calls,avg_us,min_us,max_us,total_ms,timed_calls,timed_avg_us,timed_median_us,timed_min_us,timed_max_us\n')
+        rows = []
+        for k, v in per.items():
+            v.sort()
+            dur = [(e - b) / 1e3 for b, e in v]
+            n = len(dur)
+            drop = n * W // (W + K) if (n % (W + K) == 0 and n >= W + K) else (1 if n > 1 else 0)
+            t = dur[drop:]
+            rows.append((sum(dur), '%s,%d,%.1f,%.1f,%.1f,%.3f,%d,%.1f,%.1f,%.1f,%.1f\n' % (
+                k, n, sum(dur) / n, min(dur), max(dur), sum(dur) / 1e3, len(t), sum(t) / len(t), statistics.median(t), min(t), max(t))))
+        for _, line in sorted(rows, reverse=True):
+            o.write(line)
+            print(line, end='')
+
+
 def main():
+    if sys.argv[1] == 'trace':
+        return trace_stats()
     tag, stats_dir = sys.argv[1], sys.argv[2]
     here = os.path.dirname(os.path.abspath(__file__))
     out = {}

@@ -151,6 +151,37 @@ def test_step03_cli_two_worker_ranks(files):
             np.testing.assert_array_equal(a[v].values, b[v].values, err_msg=v)
 
 
+def test_step03_24_hourly_files_two_ranks(tmp_path):
+    """BASELINE.json configs[2] in rehearsal: 24 hourly ERA5 files (small grid) through `step_03 -p 2` - files dealt
+    round-robin to two self-spawned worker ranks (both on GPU 0 of a 1-GPU box), every output file against the
+    reference-dtype oracle with its own pass count (reference parallel.py:18-32, step_03_apply_to_era.py:590-638)."""
+    from pgw4era5_amd import synthetic, step_03_apply_to_era as s3, ncio
+    base = synthetic.make_case(8, 12, 24, seed=100, dtype=np.float32, target_dt=dt.datetime(2006, 1, 15, 0))
+    cases = []
+    for h in range(24):
+        c = dict(base)
+        rng = np.random.default_rng(100 + h)             # seed 100 + file index (SURVEY 8d)
+        era = dict(base['era'])
+        era['PS'] = (base['era']['PS'] * (1 + 0.004 * rng.standard_normal(base['era']['PS'].shape))).astype(np.float32)
+        era['T'] = (base['era']['T'] + rng.standard_normal(base['era']['T'].shape).astype(np.float32)).astype(np.float32)
+        c['era'] = era
+        c['target_dt'] = dt.datetime(2006, 1, 15, 0) + dt.timedelta(hours=h)      # crosses a delta record at 12:00
+        synthetic.write_case_files(c, str(tmp_path / 'era'), str(tmp_path / 'deltas'))
+        cases.append(c)
+    out_dir = str(tmp_path / 'out')
+    n_iters = s3._cli(['-i', str(tmp_path / 'era'), '-o', out_dir, '-d', str(tmp_path / 'deltas'),
+                       '-f', '2006011500', '-l', '2006011523', '-H', '1', '-p', '2', '-t'])
+    assert len(n_iters) == 24
+    for c, n in zip(cases, n_iters):
+        want = _oracle(c)
+        assert n == want['n_iter'], c['target_dt']
+        ds = ncio.open_dataset(os.path.join(out_dir, 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])), decode_times=False)
+        np.testing.assert_allclose(ds['PS'].values, want['PS'], rtol=1.3e-7, err_msg=str(c['target_dt']))
+        np.testing.assert_allclose(ds['T'].values, want['T'], rtol=1e-9, atol=1e-9)
+        scale = np.nanmax(np.abs(want['QV']), axis=(2, 3), keepdims=True)
+        assert np.nanmax(np.abs(ds['QV'].values - want['QV']) / scale) < 6e-7
+
+
 def test_step03_cli_raw_io_path_is_byte_identical(files, monkeypatch):
     """The driver's default I/O path (file bytes pread into pinned buffers, uploaded big-endian, byte order
     converted on the GPU both ways) against PGW_IO_RAW=0 (byte order converted on the host): identical output

@@ -297,6 +297,52 @@ def test_itermp_world_size_2_gloo(tmp_path):
     assert [o[1] for o in out] == [0, 1, 0, 1, 0, 1, 0]
 
 
+def _dying_task(x):
+    if x == 1:
+        os._exit(7)                      # dies like a GPU fault / abort inside the native library: no exception, no message
+    return x
+
+
+def test_spawned_worker_that_dies_silently_fails_the_run(monkeypatch):
+    """a worker that exits without posting must make `-p N` fail, not hang."""
+    from pgw4era5_amd.parallel import IterMP
+    monkeypatch.setenv('PGW_WORKER_GRACE_S', '0.5')
+    imp = IterMP(njobs=2)
+    with pytest.raises(RuntimeError) as e:
+        imp.run(_dying_task, {}, [dict(x=i) for i in range(4)])
+    assert 'exited with code 7' in str(e.value)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself (child torch.distributed.run, gloo here,
+    no GPU work: --dry-run) and relays their line; a WORLD_SIZE that contradicts --gpus is an error."""
+    import json
+    env = dict(os.environ, PGW_BENCH_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['collective']['ranks_counted_by_all_reduce'] == 2
+    assert line['collective']['backend'] == 'gloo' and line['dry_run'] is True
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'],
+                       capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0'))
+    assert r.returncode == 2 and 'WORLD_SIZE is 1' in r.stderr
+
+
+def test_bench_cpu_baseline_legs():
+    """The two legs of bench.py's cpu_baseline (one process, file-parallel processes) on a toy file."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    from pgw4era5_amd import synthetic
+    case = synthetic.make_case(nlat=12, nlon=16, nlev=20, seed=3)
+    a = argparse.Namespace(cpu_rows=6, nlat=12, nlon=16, cpu_procs=2)
+    res = bench.cpu_baseline(case, a, np)
+    assert res['cores'] == 1 and res['kind'] == 'port' and res['value'] > 0
+    assert res['parallel']['cores'] == 2 and res['parallel']['value'] > 0
+
+
 def test_cli_argument_surface():
     from pgw4era5_amd import step_03_apply_to_era as s3, step_02_preproc_deltas as s2
     with pytest.raises(ValueError) as e:
