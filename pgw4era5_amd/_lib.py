@@ -33,6 +33,7 @@ PGW_ERR_HIP = 1
 PGW_ERR_ARG = 2
 PGW_ERR_PREF_AT_TOP = 14
 PGW_ERR_PS_HIST_ABOVE_TOP = 15
+PGW_ERR_NOT_CONVERGED = 17
 
 _vp, _i, _ll, _d, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_double, C.c_size_t
 _dp = C.POINTER(C.c_double)

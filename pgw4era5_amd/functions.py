@@ -74,13 +74,33 @@ def _dev(ctx, x, dtype, shape=None):
 
 
 def _out(ctx, dev, like):
-    """Return `dev` in the kind of `like`."""
+    """Return `dev` in the kind of `like`: DeviceArray as it is; a labelled array re-wrapped with `like`'s dimension
+    names and coordinates - `ncio.Field.like(data)`, or `.copy(data=...)` of an `xarray.DataArray` (and anything else
+    that offers it), so that the reference's own next line, e.g. `.transpose(TIME_ERA, LEV_ERA, LAT_ERA, LON_ERA)`
+    (step_03_apply_to_era.py:91-94), keeps working; a plain ndarray otherwise."""
     if isinstance(like, DeviceArray):
         return dev
     host = dev.numpy()
-    if _is_labelled(like) and hasattr(like, 'like'):
-        return like.like(host)
+    if _is_labelled(like):
+        if hasattr(like, 'like'):
+            return like.like(host)
+        if hasattr(like, 'copy') and tuple(getattr(like, 'shape', ())) == host.shape:
+            try:
+                return like.copy(data=host)
+            except TypeError:
+                pass
     return host
+
+
+def _aligned(x, like):
+    """A labelled operand whose dimensions are those of `like` in another order is transposed to `like`'s order (xarray
+    aligns operands by dimension NAME; the kernels take positions).  Anything else passes through."""
+    if x is None or not (_is_labelled(x) and _is_labelled(like)):
+        return x
+    dx, dl = tuple(x.dims), tuple(like.dims)
+    if dx != dl and sorted(dx) == sorted(dl) and hasattr(x, 'transpose'):
+        return x.transpose(*dl)
+    return x
 
 
 def _shape4(x):
@@ -94,6 +114,7 @@ def _shape4(x):
 def specific_to_relative_humidity(hus, pa, ta):
     """RH [%] from specific humidity (IFS 7.92/7.93).  reference functions.py:107-116."""
     ctx = default_context()
+    pa, ta = _aligned(pa, hus), _aligned(ta, hus)
     dt = _common_dtype(hus, pa, ta)
     shp = _raw(hus).shape
     dh, dp_, dt_ = _dev(ctx, hus, dt), _dev(ctx, np.broadcast_to(_raw(pa), shp) if not isinstance(_raw(pa), DeviceArray) else pa, dt), _dev(ctx, ta, dt)
@@ -105,6 +126,7 @@ def specific_to_relative_humidity(hus, pa, ta):
 def relative_to_specific_humidity(hur, pa, ta):
     """Specific humidity from RH [%].  reference functions.py:118-125."""
     ctx = default_context()
+    pa, ta = _aligned(pa, hur), _aligned(ta, hur)
     dt = _common_dtype(hur, pa, ta)
     shp = _raw(hur).shape
     dh, dp_, dt_ = _dev(ctx, hur, dt), _dev(ctx, np.broadcast_to(_raw(pa), shp) if not isinstance(_raw(pa), DeviceArray) else pa, dt), _dev(ctx, ta, dt)
@@ -139,6 +161,7 @@ def integ_geopot(pa_hl, zgs, ta, hus, level1, p_ref, full_column=True):
     reference functions.py:128-189.  `level1` = half-level labels (its length must be N+1).
     p_ref: scalar or (time, lat, lon) field.  Returns (time, lat, lon)."""
     ctx = default_context()
+    hus = _aligned(hus, ta)
     s = _shape4(pa_hl)
     st = _shape4(ta)
     if len(level1) != s[1] or st[1] != s[1] - 1 or _shape4(hus) != st:

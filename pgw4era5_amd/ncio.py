@@ -70,9 +70,10 @@ class Field:
 class Dataset:
     """Variables (name -> Field), dimension coordinates and global attributes of one file."""
 
-    def __init__(self, variables=None, attrs=None):
+    def __init__(self, variables=None, attrs=None, record_dim=None):
         self.variables = dict(variables or {})
         self.attrs = dict(attrs or {})
+        self.record_dim = record_dim          # name of the unlimited dimension of the file (kept by to_netcdf), or None
 
     def __contains__(self, name):
         return name in self.variables
@@ -90,6 +91,8 @@ class Dataset:
         del self.variables[name]
 
     def __getattr__(self, name):
+        if name == 'record_dim':              # Datasets unpickled / built before the attribute existed
+            return None
         try:
             return self.__dict__['variables'][name]
         except KeyError:
@@ -153,6 +156,45 @@ def decode_cf_time(values, units, calendar='standard'):
         rem = int(round(rem))
         out.append(np.datetime64('%04d-%02d-%02d' % (yy, mm, dd), 's') + np.timedelta64(rem, 's'))
     return np.array(out, dtype='datetime64[s]').reshape(np.shape(values))
+
+
+# ------------------------------------------------------------------------------ CF mask and scale
+def _float_dtype_for(dtype, has_offset):
+    """xarray.coding.variables._choose_float_dtype (2022.12): the dtype packed / masked data decode to."""
+    if dtype.kind == 'f' and dtype.itemsize <= 4:
+        return np.dtype('float32')
+    if dtype.kind in 'iu' and dtype.itemsize <= 2 and not has_offset:
+        return np.dtype('float32')
+    return np.dtype('float64')
+
+
+def mask_and_scale(values, attrs):
+    """What `xr.open_dataset` does by default (the reference reads the delta files that way, functions.py:203):
+    `_FillValue` / `missing_value` -> NaN, then `* scale_factor + add_offset`, in xarray's choice of float dtype.
+    Returns (values, attrs without the four encoding attributes).  Non-numeric data and variables without any of the
+    attributes pass through untouched (float arrays are modified in place)."""
+    keys = ('_FillValue', 'missing_value', 'scale_factor', 'add_offset')
+    if values.dtype.kind not in 'fiu' or not any(k in attrs for k in keys):
+        return values, attrs
+    fills = []
+    for k in ('_FillValue', 'missing_value'):
+        if k in attrs:
+            fills += [x for x in np.atleast_1d(np.asarray(attrs[k])).tolist() if not (isinstance(x, float) and x != x)]
+    scale, offset = attrs.get('scale_factor'), attrs.get('add_offset')
+    out_dt = _float_dtype_for(values.dtype, offset is not None) if (fills or scale is not None or offset is not None) else values.dtype
+    mask = None
+    for f in fills:
+        m = values == np.asarray(f).astype(values.dtype)
+        mask = m if mask is None else (mask | m)
+    if values.dtype != out_dt:
+        values = values.astype(out_dt)
+    if mask is not None and mask.any():
+        values[mask] = np.nan
+    if scale is not None:
+        values *= np.asarray(scale).reshape(-1)[0]
+    if offset is not None:
+        values += np.asarray(offset).reshape(-1)[0]
+    return values, {k: v for k, v in attrs.items() if k not in keys}
 
 
 # ------------------------------------------------------------------------------ file I/O
@@ -286,9 +328,11 @@ def _pread_into(fd, buf, offset):
         mv = mv[n:]
 
 
-def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None):
+def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, decode_mask_scale=None):
     """Read a NetCDF-3 file completely into memory (`xr.open_dataset(...).load()`).
-    decode_times=False corresponds to the reference's `decode_cf=False` (step_03:60).
+    decode_times=False corresponds to the reference's `decode_cf=False` (step_03:60: the ERA5 file is taken raw);
+    the default decodes like a plain `xr.open_dataset` (the delta files, functions.py:203): CF times AND
+    `_FillValue` / `missing_value` -> NaN, `scale_factor` / `add_offset` applied (`decode_mask_scale`, default = decode_times).
 
     Every variable is `pread` into its array (large ones concurrently) and converted from the file's big-endian
     layout in place.  With `raw_big=True` variables of at least BIG_VARIABLE bytes are NOT converted: their
@@ -297,8 +341,10 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None):
     PGW_NC_READER=scipy selects the previous reader built on scipy.io.netcdf_file."""
     import os
     from concurrent.futures import ThreadPoolExecutor
+    if decode_mask_scale is None:
+        decode_mask_scale = decode_times
     if os.environ.get('PGW_NC_READER') == 'scipy':
-        return _open_dataset_scipy(path, decode_times, threads)
+        return _open_dataset_scipy(path, decode_times, threads, decode_mask_scale)
     fd = os.open(path, os.O_RDONLY)
     try:
         try:
@@ -335,7 +381,11 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None):
                 data[v['name']] = read(v)
     finally:
         os.close(fd)
-    ds = Dataset(attrs=hdr['attrs'])
+    rec_dims = [n for n, length in hdr['dims'] if length == 0]
+    ds = Dataset(attrs=hdr['attrs'], record_dim=rec_dims[0] if rec_dims else None)
+    if decode_mask_scale:
+        for v in hdr['vars']:
+            data[v['name']], v['attrs'] = mask_and_scale(data[v['name']], v['attrs'])
     coords = {}
     for v in hdr['vars']:
         if v['dims'] == (v['name'],):
@@ -350,7 +400,7 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None):
     return ds
 
 
-def _open_dataset_scipy(path, decode_times=True, threads=4):
+def _open_dataset_scipy(path, decode_times=True, threads=4, decode_mask_scale=None):
     """The reader of the first version: scipy.io.netcdf_file over a memory map, every variable converted to a
     native-endian copy."""
     from concurrent.futures import ThreadPoolExecutor
@@ -383,6 +433,11 @@ def _open_dataset_scipy(path, decode_times=True, threads=4):
             nc.close()
         except Exception:           # scipy complains if views of the map are still alive; all data were copied
             pass
+    if decode_mask_scale or (decode_mask_scale is None and decode_times):
+        for name in list(raw):
+            data, dims, attrs = raw[name]
+            data, attrs = mask_and_scale(data, attrs)
+            raw[name] = (data, dims, attrs)
     coords = {}
     for name, (data, dims, attrs) in raw.items():
         if dims == (name,):
@@ -437,15 +492,44 @@ def _nc_atts(attrs):
     return out
 
 
+def _nc_header(attrs, dims, record_dim, numrecs, specs, begins, dim_ids):
+    """Bytes of a CDF-2 (64-bit offset) header.  specs: dicts with name, dims, attrs, key (numpy dtype code), vsize."""
+    import struct
+    h = b'CDF\x02' + struct.pack('>i', numrecs)
+    if dims:
+        h += struct.pack('>ii', 0x0A, len(dims))
+        for d, n in dims.items():
+            h += _nc_name(d) + struct.pack('>i', 0 if d == record_dim else n)
+    else:
+        h += b'\x00' * 8
+    h += _nc_atts(attrs)
+    if specs:
+        h += struct.pack('>ii', 0x0B, len(specs))
+        for sp, b in zip(specs, begins):
+            h += _nc_name(sp['name']) + struct.pack('>i', len(sp['dims']))
+            for d in sp['dims']:
+                h += struct.pack('>i', dim_ids[d])
+            h += _nc_atts(sp['attrs'])
+            # vsize is an UNSIGNED 32-bit field; sizes that do not fit are written as 2^32 - 1 (the CDF-2 convention:
+            # readers recompute the size of such variables from their shape - this module's reader always does)
+            h += struct.pack('>iI', _NC_TYPE[sp['key']], sp['vsize'] if sp['vsize'] < 2 ** 32 else 0xFFFFFFFF)
+            h += struct.pack('>q', b)
+    else:
+        h += b'\x00' * 8
+    return h
+
+
 def to_netcdf(ds, path, threads=None):
     """Write a Dataset as NetCDF-3 64-bit-offset (`.to_netcdf(path, mode='w')`, step_03:378).
 
-    Native writer (the classic format is a header + fixed-size big-endian arrays): every variable
-    is byte-swapped in one pass (not at all if it is already big-endian) and written with `os.pwrite`
-    at its offset, large variables in 64 MiB pieces on `threads` threads - scipy's writer makes three copies of every array under the GIL and was the
-    bottleneck of the whole command line (1.06 s per 2.3 GB file; PGW_NC_WRITER=scipy selects it)."""
+    Native writer (the classic format is a header + big-endian arrays): every variable is byte-swapped in one pass (not
+    at all if it is already big-endian) and written with `os.pwrite` at its offset, large variables in 64 MiB pieces on
+    `threads` threads - scipy's writer makes three copies of every array under the GIL and was the bottleneck of the
+    whole command line (1.06 s per 2.3 GB file; PGW_NC_WRITER=scipy selects it).
+    `ds.record_dim` (set by open_dataset from the input file's unlimited dimension): variables whose first dimension it
+    is are written as record variables - dimension length 0 in the header, `numrecs` records interleaved after the
+    fixed-size variables - so the ERA5 file keeps its unlimited `time` like the reference's `to_netcdf` does."""
     import os
-    import struct
     from concurrent.futures import ThreadPoolExecutor
     if os.environ.get('PGW_NC_WRITER') == 'scipy':
         return _to_netcdf_scipy(ds, path)
@@ -458,6 +542,8 @@ def to_netcdf(ds, path, threads=None):
                 raise ValueError('dimension %s has inconsistent lengths %d and %d' % (d, dims[d], n))
             dims.setdefault(d, int(n))
     dim_ids = {d: i for i, d in enumerate(dims)}
+    record_dim = ds.record_dim if ds.record_dim in dims else None
+    numrecs = dims[record_dim] if record_dim else 0
     # variables: data converted lazily (dtype decided here)
     specs = []
     for name, f in ds.variables.items():
@@ -474,52 +560,45 @@ def to_netcdf(ds, path, threads=None):
         key = data.dtype.str[1:]
         if key not in _NC_TYPE or key == 'S1':
             raise TypeError('variable %s: dtype %s cannot be stored in NetCDF-3' % (name, data.dtype))
+        record = record_dim is not None and len(f.dims) > 0 and f.dims[0] == record_dim
         nbytes = int(data.size) * data.dtype.itemsize
-        specs.append(dict(name=name, f=f, data=data, attrs=attrs, key=key, nbytes=nbytes, vsize=nbytes + (-nbytes % 4)))
+        per = nbytes // numrecs if (record and numrecs) else (0 if record else nbytes)      # bytes per record / of the variable
+        specs.append(dict(name=name, dims=f.dims, data=data, attrs=attrs, key=key, nbytes=nbytes, record=record, per=per,
+                          vsize=per + (-per % 4)))
+    recs = [sp for sp in specs if sp['record']]
+    if len(recs) == 1:
+        recs[0]['vsize'] = recs[0]['per']                       # a single record variable is not padded (classic format rule)
+    recsize = sum(sp['vsize'] for sp in recs)
 
-    def header(begins):
-        h = b'CDF\x02' + struct.pack('>i', 0)
-        if dims:
-            h += struct.pack('>ii', 0x0A, len(dims))
-            for d, n in dims.items():
-                h += _nc_name(d) + struct.pack('>i', n)
-        else:
-            h += b'\x00' * 8
-        h += _nc_atts(ds.attrs)
-        if specs:
-            h += struct.pack('>ii', 0x0B, len(specs))
-            for sp, b in zip(specs, begins):
-                h += _nc_name(sp['name']) + struct.pack('>i', len(sp['f'].dims))
-                for d in sp['f'].dims:
-                    h += struct.pack('>i', dim_ids[d])
-                h += _nc_atts(sp['attrs'])
-                h += struct.pack('>ii', _NC_TYPE[sp['key']], min(sp['vsize'], 0xFFFFFFFF - 3) if sp['vsize'] < 2 ** 32 else -1)
-                h += struct.pack('>q', b)
-        else:
-            h += b'\x00' * 8
-        return h
+    def layout(hlen):
+        begins, off = [None] * len(specs), hlen
+        for i, sp in enumerate(specs):                           # fixed-size variables first, in header order
+            if not sp['record']:
+                begins[i] = off
+                off += sp['vsize']
+        for i, sp in enumerate(specs):                           # then the first record
+            if sp['record']:
+                begins[i] = off
+                off += sp['vsize']
+        return begins, off + recsize * max(numrecs - 1, 0)
 
-    hlen = len(header([0] * len(specs)))
-    begins, off = [], hlen
-    for sp in specs:
-        begins.append(off)
-        off += sp['vsize']
-    hdr = header(begins)
+    hlen = len(_nc_header(ds.attrs, dims, record_dim, numrecs, specs, [0] * len(specs), dim_ids))
+    begins, total = layout(hlen)
+    hdr = _nc_header(ds.attrs, dims, record_dim, numrecs, specs, begins, dim_ids)
     assert len(hdr) == hlen
     fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     try:
-        os.ftruncate(fd, off)
+        os.ftruncate(fd, total)
         os.pwrite(fd, hdr, 0)
         CH = 64 << 20                                            # swap + write in 64 MiB pieces
         flats = [np.ascontiguousarray(sp['data']).reshape(-1) for sp in specs]
 
         def write_piece(task):
-            i, s0, s1 = task
+            i, s0, s1, pos = task
             flat = flats[i]
             # one pass: copy + byte swap; no copy at all if the data are already big-endian (raw I/O path)
             chunk = flat[s0:s1].astype(flat.dtype.newbyteorder('>'), copy=False)
             mv = memoryview(chunk).cast('B')
-            pos = begins[i] + s0 * flat.dtype.itemsize
             while len(mv):
                 n = os.pwrite(fd, mv, pos)
                 pos += n
@@ -528,11 +607,20 @@ def to_netcdf(ds, path, threads=None):
 
         tasks, small = [], []
         for i, sp in enumerate(specs):
-            if sp['nbytes'] >= BIG_VARIABLE:
-                step = max(CH // max(flats[i].dtype.itemsize, 1), 1)
-                tasks += [(i, s0, min(s0 + step, flats[i].size)) for s0 in range(0, flats[i].size, step)]
-            elif flats[i].size:
-                small.append((i, 0, flats[i].size))
+            item = flats[i].dtype.itemsize
+            if sp['record']:                                     # record r of the variable starts at begin + r * recsize
+                n_el = sp['per'] // item
+                pieces = [(r * n_el, (r + 1) * n_el, begins[i] + r * recsize) for r in range(numrecs)]
+            else:
+                pieces = [(0, flats[i].size, begins[i])]
+            for e0, e1, pos in pieces:
+                if e1 <= e0:
+                    continue
+                if (e1 - e0) * item >= BIG_VARIABLE:
+                    step = max(CH // max(item, 1), 1)
+                    tasks += [(i, s0, min(s0 + step, e1), pos + (s0 - e0) * item) for s0 in range(e0, e1, step)]
+                else:
+                    small.append((i, e0, e1, pos))
         if len(tasks) > 1 and threads > 1:
             with ThreadPoolExecutor(max_workers=min(threads, len(tasks))) as pool:
                 list(pool.map(write_piece, tasks))

@@ -449,7 +449,7 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
     if 'akm' in era_file:                                                    # step_03:68-70
         coeffs['akm'] = np.asarray(era_file['akm'].values, dtype=np.float64)
         coeffs['bkm'] = np.asarray(era_file['bkm'].values, dtype=np.float64)
-    return dict(era_file=era_file, era=era, coeffs=coeffs, dtype=dtype, out_path=out_era_file_path,
+    return dict(era_file=era_file, era=era, coeffs=coeffs, dtype=dtype, out_path=out_era_file_path, inp_path=inp_era_file_path,
                 delta_input_dir=delta_input_dir, era_step_dt=era_step_dt, ignore_top=ignore_top_pressure_error,
                 dims=dict(d3=dims3, d4=dims4, so=dims_so), pinned=pinned)
 
@@ -471,8 +471,16 @@ def _stage_compute(item):
             bufs['inp'][k] = ctx.empty(v.shape, dtype)
         bufs['inp'][k].copy_from(v, sync=False)             # host arrays stay alive in `item` until the sync below
     run = process_file_device_reinterp if S.i_reinterp else process_file_device
-    out, info = run(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
-                    p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
+    try:
+        out, info = run(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
+                        p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
+    except ValueError as e:
+        if getattr(e, 'status', None) == _lib.PGW_ERR_NOT_CONVERGED or str(e).startswith('ERROR! Pressure adjustment did not converge'):
+            raise ValueError('ERROR! Pressure adjustment did not converge ' +                   # step_03:315-319, text and file name
+                             'for file {}. '.format(item.get('inp_path')) +
+                             'Consider increasing the value for "max_n_iter" in ' +
+                             'settings.py') from None
+        raise
     raw = _io_raw()
     pool = _pinned_pool(ctx) if raw else None
     result, pinned_out = {}, []

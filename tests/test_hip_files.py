@@ -54,6 +54,51 @@ def test_step03_cli_end_to_end(files):
         np.testing.assert_array_equal(ds['ak'].values, c['era']['ak'])
 
 
+def test_step03_fill_value_encoded_deltas(tmp_path):
+    """delta files as xarray re-encodes CMIP sources - tos over land and ta below ground carry _FillValue
+    1e20 instead of NaN.  The driver must decode them like the reference's xr.open_dataset (functions.py:203): same
+    output as the same run with NaN-valued files, = the oracle fed NaNs."""
+    from pgw4era5_amd import synthetic, step_03_apply_to_era as s3, ncio
+    c = synthetic.make_case(6, 8, 12, seed=21, dtype=np.float32, target_dt=dt.datetime(2006, 8, 2, 6))
+    assert np.isnan(c['deltas']['tos']).any()
+    # "below ground": NaN in the two lowest plev of some columns of the ua delta (ua has no surface insertion)
+    c['deltas']['ua'][:, :2, 1:3, 2:5] = np.nan
+    synthetic.write_case_files(c, str(tmp_path / 'era'), str(tmp_path / 'deltas'))
+    for var in ('tos', 'ua'):                                   # re-encode NaN as a 1e20 fill value with the CF attribute
+        path = str(tmp_path / 'deltas' / ('%s_delta.nc' % var))
+        ds = ncio.open_dataset(path, decode_times=False)
+        v = ds[var].values.copy()
+        v[np.isnan(v)] = np.float32(1e20)
+        ds[var] = ncio.Field(v, ds[var].dims, ds[var].coords, dict(ds[var].attrs, _FillValue=np.float32(1e20)))
+        ncio.to_netcdf(ds, path)
+        assert not np.isnan(ncio.open_dataset(path, decode_times=False)[var].values).any()
+    s3._DELTASETS.clear()
+    out_dir = str(tmp_path / 'out')
+    s3._cli(['-i', str(tmp_path / 'era'), '-o', out_dir, '-d', str(tmp_path / 'deltas'),
+             '-f', '2006080206', '-l', '2006080206', '-H', '3', '-p', '1', '-t'])
+    s3._DELTASETS.clear()
+    want = _oracle(c)
+    ds = ncio.open_dataset(os.path.join(out_dir, 'cas2006080206' + '0000.nc'), decode_times=False)
+    np.testing.assert_allclose(ds['T_SKIN'].values, want['T_SKIN'], rtol=1.3e-7, equal_nan=True)
+    assert np.nanmax(ds['T_SKIN'].values) < 400.0                 # no 1e20 blended into the skin temperature
+    np.testing.assert_allclose(ds['T_SO'].values, want['T_SO'], rtol=1.3e-7, equal_nan=True)
+    np.testing.assert_allclose(ds['U'].values, want['U'], rtol=1e-9, atol=1e-9, equal_nan=True)
+    assert np.isnan(ds['U'].values).sum() == np.isnan(want['U']).sum() > 0
+
+
+def test_step03_non_convergence_names_the_file(files, monkeypatch):
+    """step_03_apply_to_era.py:315-319: the error names the input file and the setting to raise."""
+    from pgw4era5_amd import step_03_apply_to_era as s3, settings as S
+    root, cases = files
+    monkeypatch.setattr(S, 'max_n_iter', 2)
+    with pytest.raises(ValueError) as e:
+        s3._cli(['-i', str(root / 'era'), '-o', str(root / 'out_nc'), '-d', str(root / 'deltas'),
+                 '-f', '2006080200', '-l', '2006080200', '-H', '3', '-t'])
+    inp = os.path.join(str(root / 'era'), 'cas20060802000000.nc')
+    assert str(e.value) == ('ERROR! Pressure adjustment did not converge for file {}. Consider increasing the value for '
+                            '"max_n_iter" in settings.py'.format(inp))
+
+
 def test_step03_top_pressure_error_without_t(files):
     from pgw4era5_amd import step_03_apply_to_era as s3
     root, cases = files

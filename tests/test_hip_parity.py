@@ -363,6 +363,134 @@ def test_regrid_block_window_paths(F, case):
     assert np.isnan(want).sum() > 0 or case in ('coarse_target', 'unsorted_lons')     # a coarse target may miss the NaN cell
 
 
+def test_regrid_full_size_config4_properties_and_band(F):
+    """BASELINE.json configs[3] at full size: one 19-level variable x 12 months from an MPI-ESM1-2-HR-like 192 x 384
+    Gaussian grid (lats short of the poles, lon 0 ... 359.0625) to the ERA5 0.25 deg grid (721 x 1440), through
+    regrid_field on the GPU.  The oracle needs minutes for 237 M outputs, so the full result is checked through
+    size-independent properties (functions.py:817-893) and a 6-row band of it against the oracle."""
+    from pgw4era5_amd import synthetic
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    g = synthetic.make_gcm_grid_case(nlat_src=192, nlon_src=384, nlat=721, nlon=1440, nplev=19, ntime=12, seed=4)
+    f, slat, slon, tlat, tlon = g['field'], g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon']
+    nt, npl = f.shape[:2]
+    # plane (0,0): zonally constant (depends on latitude only); (0,1): linear in latitude; (0,2): linear in longitude;
+    # (0,3): one NaN cell; the rest random
+    f[0, 0] = np.sin(np.deg2rad(slat))[:, None] * np.ones(len(slon))
+    f[0, 1] = (2.0 + 0.25 * slat)[:, None] * np.ones(len(slon))
+    f[0, 2] = np.ones(len(slat))[:, None] * (1.0 + 0.125 * slon)[None, :]
+    f[0, 3, 100, 200] = np.nan
+    d_src = ctx.to_device(f)
+    d_out = F.regrid_field(d_src, slat, slon, tlat, tlon)
+    got = d_out.numpy()
+    d_src.free(); d_out.free()
+    assert got.shape == (nt, npl, 721, 1440)
+    # --- zonally constant in, zonally constant out, equal to the 1-D latitude interpolation (pole rows: the zonal mean
+    # of the nearest source row = the row's own constant)
+    zc = got[0, 0]
+    assert np.ptp(zc, axis=1).max() == 0.0
+    lat_ext = np.concatenate([[-90.0], slat, [90.0]])
+    col_ext = np.concatenate([[f[0, 0, 0, 0]], f[0, 0, :, 0], [f[0, 0, -1, 0]]])
+    np.testing.assert_allclose(zc[:, 0], O.interp1d_linear(lat_ext, col_ext, tlat, axis=0), rtol=1e-14, atol=1e-15)
+    # --- linear in latitude: exact inside the source latitudes; beyond them the pole row (zonal mean of the last row)
+    # makes it constant (functions.py:833-842)
+    inside = (tlat >= slat[0]) & (tlat <= slat[-1])
+    np.testing.assert_allclose(got[0, 1][inside], (2.0 + 0.25 * tlat[inside])[:, None] * np.ones(1440), rtol=1e-13)
+    np.testing.assert_allclose(got[0, 1][tlat > slat[-1]], 2.0 + 0.25 * slat[-1], rtol=1e-13)
+    np.testing.assert_allclose(got[0, 1][tlat < slat[0]], 2.0 + 0.25 * slat[0], rtol=1e-13)
+    # --- linear in longitude: exact up to the last source longitude; in the periodic gap 359.0625 ... 360 the copy at
+    # lon + 360 closes the circle (functions.py:866-874): interpolation between the last and the first source column
+    # (rows between the last source latitude and the pole blend towards the pole row's zonal mean: `inside` rows only)
+    lin = got[0, 2][inside]
+    west = tlon <= slon[-1]
+    np.testing.assert_allclose(lin[:, west], np.ones(len(lin))[:, None] * (1.0 + 0.125 * tlon[west])[None, :], rtol=1e-13)
+    gap = ~west
+    assert gap.sum() == 3                                   # 359.25, 359.5, 359.75
+    y_last, y_first = 1.0 + 0.125 * slon[-1], 1.0 + 0.125 * slon[0]
+    want_gap = (y_first - y_last) / ((slon[0] + 360) - slon[-1]) * (tlon[gap] - slon[-1]) + y_last
+    np.testing.assert_allclose(lin[:, gap], np.ones(len(lin))[:, None] * want_gap[None, :], rtol=1e-13)
+    # --- pole rows of every plane: the zonal mean (NaN-skipping) of the first / last source row, on every longitude
+    rnd = got[5, 7]
+    np.testing.assert_allclose(rnd[0], np.full(1440, f[5, 7, 0].mean()), rtol=1e-13)
+    np.testing.assert_allclose(rnd[-1], np.full(1440, f[5, 7, -1].mean()), rtol=1e-13)
+    # --- NaN propagation: exactly the targets whose 2 x 2 stencil touches source cell (100, 200)
+    nanmask = np.isnan(got[0, 3])
+    jj = np.nonzero((tlat > slat[99]) & (tlat < slat[101]))[0]
+    ii = np.nonzero((tlon > slon[199]) & (tlon < slon[201]))[0]
+    want_mask = np.zeros_like(nanmask)
+    want_mask[np.ix_(jj, ii)] = True
+    np.testing.assert_array_equal(nanmask, want_mask)
+    assert not np.isnan(np.delete(got.reshape(nt * npl, 721, 1440), 3, axis=0)).any()
+    # --- a 6-row band (both pole rows, two rows around the equator, two mid-latitude rows) of all 228 planes vs the oracle
+    rows = np.array([0, 1, 360, 361, 612, 720])
+    want = O.regrid_lat_lon(f, slat, slon, tlat[rows], tlon)
+    np.testing.assert_allclose(got[:, :, rows], want, rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
+class FakeDataArray:
+    """Stand-in for xarray.DataArray (not installable here): `.values/.dims/.coords/.shape/.dtype`, `.copy(data=)`,
+    `.transpose(*dims)`, `.isel`, `len()` - what the reference's step_03 lines touch on the results of the functions
+    below.  NOT an ncio.Field: no `.like`, so functions._out must take the `.copy(data=)` route."""
+
+    def __init__(self, values, dims, coords=None):
+        self.values = np.asarray(values)
+        self.dims = tuple(dims)
+        self.coords = dict(coords or {})
+        assert self.values.ndim == len(self.dims)
+
+    shape = property(lambda self: self.values.shape)
+    dtype = property(lambda self: self.values.dtype)
+
+    def __len__(self):
+        return self.values.shape[0]
+
+    def copy(self, deep=True, data=None):
+        v = self.values.copy() if data is None else np.asarray(data)
+        if v.shape != self.values.shape:
+            raise ValueError('replacement data must match the shape')
+        return FakeDataArray(v, self.dims, self.coords)
+
+    def transpose(self, *dims):
+        return FakeDataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, self.coords)
+
+
+def test_functions_rewrap_xarray_like_inputs(F):
+    """INTEGRATION.md section A (import swap): the reference's own call sequence on labelled arrays that are not this
+    package's Field - step_03_apply_to_era.py:87-94 (RELHUM of the ERA state followed by `.transpose(dim names)`),
+    :262-287 (hus_pgw, integ_geopot of both states with `era_file[HLEV_ERA]` as level1) - returns labelled arrays
+    with the inputs' dims / coords, and operands given in another dimension order are aligned by NAME."""
+    c = _case(5, 7, 12, seed=3)
+    era = c['era']
+    d4, d4h, d3 = ('time', 'level', 'lat', 'lon'), ('time', 'level1', 'lat', 'lon'), ('time', 'lat', 'lon')
+    coords = dict(lat=c['lat'], lon=c['lon'])
+    W = lambda v, dims: FakeDataArray(v, dims, coords)
+    pa_hl_np, pa_np = O.hybrid_pressure(era['ak'], era['bk'], era['PS'])
+    hus, ta, pa, pa_hl = W(era['QV'], d4), W(era['T'], d4), W(pa_np, d4), W(pa_hl_np, d4h)
+    # :91-94  era_file[hur] = specific_to_relative_humidity(hus, pa_era, ta).transpose(TIME_ERA, LEV_ERA, LAT_ERA, LON_ERA)
+    hur = F.specific_to_relative_humidity(hus, pa, ta).transpose('time', 'level', 'lat', 'lon')
+    assert isinstance(hur, FakeDataArray) and hur.dims == d4 and hur.coords['lat'] is coords['lat']
+    want = O.specific_to_relative_humidity(era['QV'], pa_np, era['T'])
+    np.testing.assert_allclose(hur.values, want, rtol=1e-12)
+    # operands in another dimension order: xarray would align them by name
+    pa_t = pa.transpose('time', 'lat', 'lon', 'level')
+    hur2 = F.specific_to_relative_humidity(hus, pa_t, ta)
+    np.testing.assert_array_equal(hur2.values, hur.values)
+    # :262-266
+    q = F.relative_to_specific_humidity(hur, pa, ta)
+    assert isinstance(q, FakeDataArray) and q.dims == d4
+    np.testing.assert_allclose(q.values, era['QV'], rtol=1e-9, atol=1e-18)
+    # :269-287  integ_geopot(pa_hl, zgs, ta, hus, era_file[HLEV_ERA], p_ref) -> (time, lat, lon) labelled like zgs
+    level1 = FakeDataArray(era['level1'], ('level1',))
+    phi = F.integ_geopot(pa_hl, W(era['FIS'], d3), ta, q, level1, 30000)
+    assert isinstance(phi, FakeDataArray) and phi.dims == d3 and phi.shape == era['FIS'].shape
+    np.testing.assert_allclose(phi.values, O.integ_geopot(pa_hl_np, era['FIS'], era['T'], q.values, era['level1'], 30000), rtol=1e-12)
+    # interp_logp_4d returns the target's labels (functions.py:472 xr.zeros_like(targ_P))
+    out = F.interp_logp_4d(ta, pa, W(pa_np * 1.001, d4), extrapolate='constant')
+    assert isinstance(out, FakeDataArray) and out.dims == d4
+    # plain ndarrays still come back as ndarrays
+    assert isinstance(F.specific_to_relative_humidity(era['QV'], pa_np, era['T']), np.ndarray)
+
+
 def test_device_log_accuracy():
     """pgw_log (the logarithm every kernel uses) against numpy: <= 1 ulp on positive normal
     numbers, IEEE special cases through the ocml fallback."""

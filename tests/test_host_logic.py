@@ -248,6 +248,88 @@ def test_synthetic_files_roundtrip(tmp_path):
     assert os.path.exists(tmp_path / 'deltas' / 'ps_historical.nc')
 
 
+def test_delta_files_are_mask_and_scale_decoded(tmp_path):
+    """the reference reads the delta files with a plain xr.open_dataset (functions.py:203): _FillValue /
+    missing_value -> NaN, scale_factor / add_offset applied; the ERA5 file with decode_cf=False (step_03:60): raw."""
+    from pgw4era5_amd import ncio
+    F = ncio.Field
+    tos = np.array([[1.5, 1e20], [2.5, 3.5]], dtype=np.float32)[None]
+    ta = np.array([[[250.0, -999.0], [1e20, 260.0]]], dtype=np.float64)[None]
+    packed = np.array([[100, -32768], [200, 300]], dtype=np.int16)[None]
+    ds = ncio.Dataset()
+    ds['time'] = F(np.array([0.0]), ('time',), attrs=dict(units='days since 2000-01-01'))
+    ds['tos'] = F(tos, ('time', 'lat', 'lon'), attrs={'_FillValue': np.float32(1e20), 'units': 'K'})
+    ds['ta'] = F(ta, ('time', 'plev', 'lat', 'lon'), attrs={'_FillValue': 1e20, 'missing_value': -999.0})
+    ds['pk'] = F(packed, ('time', 'lat', 'lon'), attrs={'_FillValue': np.int16(-32768), 'scale_factor': 0.01, 'add_offset': 273.15})
+    path = str(tmp_path / 'd.nc')
+    ncio.to_netcdf(ds, path)
+    for reader in ('native', 'scipy'):
+        os.environ.pop('PGW_NC_READER', None)
+        if reader == 'scipy':
+            os.environ['PGW_NC_READER'] = 'scipy'
+        try:
+            got = ncio.open_dataset(path)                                  # like xr.open_dataset
+            raw = ncio.open_dataset(path, decode_times=False)              # like decode_cf=False
+        finally:
+            os.environ.pop('PGW_NC_READER', None)
+        assert got['tos'].dtype == np.float32 and np.isnan(got['tos'].values[0, 0, 1]) and got['tos'].values[0, 1, 1] == 3.5
+        assert '_FillValue' not in got['tos'].attrs and got['tos'].attrs['units'] == 'K'
+        assert np.isnan(got['ta'].values[0, 0, 0, 1]) and np.isnan(got['ta'].values[0, 0, 1, 0]) and got['ta'].values[0, 0, 0, 0] == 250.0
+        pk = got['pk'].values
+        assert pk.dtype == np.float64 and np.isnan(pk[0, 0, 1])            # int16 with add_offset decodes to float64
+        np.testing.assert_allclose(pk[0, 1], [200 * 0.01 + 273.15, 300 * 0.01 + 273.15], rtol=1e-15)
+        assert raw['tos'].values[0, 0, 1] == np.float32(1e20) and raw['pk'].dtype == np.int16 and raw['time'].values[0] == 0.0
+        assert raw['tos'].attrs['_FillValue'] == np.float32(1e20)
+
+
+def test_writer_keeps_the_record_dimension_and_packs_vsize_unsigned(tmp_path):
+    """(1) the unlimited `time` of the input file survives a read -> modify -> write cycle (the reference's
+    to_netcdf keeps it); records of several variables interleave as the classic format prescribes (scipy reads them
+    back); (2) vsize is an unsigned field: a 2 ... 4 GiB variable must not overflow the header packer."""
+    import struct
+    from scipy.io import netcdf_file
+    from pgw4era5_amd import ncio
+    F = ncio.Field
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(3, 2, 5)).astype(np.float32)
+    b = rng.normal(size=(3, 5))
+    ds = ncio.Dataset(record_dim='time')
+    ds['time'] = F(np.arange(3.0), ('time',))
+    ds['lon'] = F(np.arange(5.0), ('lon',))
+    ds['a'] = F(a, ('time', 'lev', 'lon'))
+    ds['fixed'] = F(np.arange(5, dtype=np.int16), ('lon',))            # odd byte count: exercises the padding
+    ds['b'] = F(b, ('time', 'lon'))
+    path = str(tmp_path / 'rec.nc')
+    ncio.to_netcdf(ds, path)
+    nc = netcdf_file(path, 'r', mmap=False)                            # independent reader
+    assert nc.dimensions['time'] is None and nc.variables['a'].isrec and nc.variables['b'].isrec and not nc.variables['fixed'].isrec
+    np.testing.assert_array_equal(nc.variables['a'][:], a)
+    np.testing.assert_array_equal(nc.variables['b'][:], b)
+    np.testing.assert_array_equal(nc.variables['fixed'][:], np.arange(5))
+    nc.close()
+    back = ncio.open_dataset(path, decode_times=False)
+    assert back.record_dim == 'time'
+    np.testing.assert_array_equal(back['a'].values, a)
+    np.testing.assert_array_equal(back['b'].values, b)
+    back['a'] = F(a * 2, ('time', 'lev', 'lon'))                       # what the step_03 driver does with T, QV, ...
+    ncio.to_netcdf(back, str(tmp_path / 'rec2.nc'))
+    again = ncio.open_dataset(str(tmp_path / 'rec2.nc'), decode_times=False)
+    assert again.record_dim == 'time'
+    np.testing.assert_array_equal(again['a'].values, a * 2)
+    # one record variable alone is not padded
+    one = ncio.Dataset(record_dim='t')
+    one['v'] = F(np.arange(6, dtype=np.int8).reshape(3, 2), ('t', 'x'))
+    ncio.to_netcdf(one, str(tmp_path / 'one.nc'))
+    nc = netcdf_file(str(tmp_path / 'one.nc'), 'r', mmap=False)
+    np.testing.assert_array_equal(nc.variables['v'][:], np.arange(6).reshape(3, 2))
+    nc.close()
+    # header packing of large variables (no data written): 3 GiB fits the unsigned field, 5 GiB is written as 2^32 - 1
+    for vsize, want in ((3 << 30, 3 << 30), (5 << 30, 0xFFFFFFFF), ((1 << 32) - 4, (1 << 32) - 4)):
+        spec = dict(name='big', dims=('x',), attrs={}, key='f8', vsize=vsize)
+        h = ncio._nc_header({}, {'x': vsize // 8}, None, 0, [spec], [1024], {'x': 0})
+        assert struct.unpack('>I', h[-12:-8])[0] == want and struct.unpack('>q', h[-8:])[0] == 1024
+
+
 def _task(x, k):
     return (x * k, int(os.environ.get('RANK', os.environ.get('PGW_RANK', '0'))))
 
