@@ -62,7 +62,9 @@ def test_step03_fill_value_encoded_deltas(tmp_path):
     c = synthetic.make_case(6, 8, 12, seed=21, dtype=np.float32, target_dt=dt.datetime(2006, 8, 2, 6))
     assert np.isnan(c['deltas']['tos']).any()
     # "below ground": NaN in the two lowest plev of some columns of the ua delta (ua has no surface insertion)
-    c['deltas']['ua'][:, :2, 1:3, 2:5] = np.nan
+    low = c['era']['PS'][0] > 95000.0                         # sea-level columns: model levels reach below 925 hPa there
+    assert low.sum() > 4
+    c['deltas']['ua'][:, :2, low] = np.nan
     synthetic.write_case_files(c, str(tmp_path / 'era'), str(tmp_path / 'deltas'))
     for var in ('tos', 'ua'):                                   # re-encode NaN as a 1e20 fill value with the CF attribute
         path = str(tmp_path / 'deltas' / ('%s_delta.nc' % var))
