@@ -1087,27 +1087,67 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
         int ci1 = -2, ci2 = -2;
         double a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;       // ta, hur
         double c_lo = 0, c_hi = 0, d_lo = 0, d_hi = 0;       // ua, va
+        // A bracket change gathers the records of the new source level(s) from global memory.  All loads of one change are
+        // issued back to back BEFORE the first use (raw values into registers, then the time interpolation): one exposed
+        // memory latency per change instead of one per value (the first version waited after every record pair - 2 to 4
+        // serial round trips per change, the largest part of the kernel's 0.51 s_waitcnt share).
+        auto tl = [&](const DeltaSrc<T> &sv, T rb, T ra) -> double {          // load_delta's time interpolation of one value
+            if (!LERP) return (double)rb;
+            const double diff = REF ? (double)(T)(ra - rb) : (double)ra - (double)rb;
+            return by_x_hi.divide(diff) * sv.x_new + (double)rb;
+        };
+        auto off_of = [&](int i) -> O { return dbase + (O)(S - 1 - i) * row; };
         auto fetch1 = [&](int i1) {
             if (ci1 == i1) return;
-            O o = dbase + (O)(S - 1 - i1) * row;
-            if (ci1 + 1 == i1) { a_lo = a_hi; b_lo = b_hi; }
-            else { a_lo = is_sfc(i1) ? sfa : sTa.template get_at<LERP, REF>(o, by_x_hi); b_lo = is_sfc(i1) ? sfb : sHur.template get_at<LERP, REF>(o, by_x_hi); }
-            int ih = (i1 + 1 < S) ? i1 + 1 : i1;
-            O oh = dbase + (O)(S - 1 - ih) * row;
-            a_hi = is_sfc(ih) ? sfa : sTa.template get_at<LERP, REF>(oh, by_x_hi);
-            b_hi = is_sfc(ih) ? sfb : sHur.template get_at<LERP, REF>(oh, by_x_hi);
+            const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+            const O oh = off_of(ih);
+            const bool seq = (ci1 + 1 == i1);
+            T hb0 = ld_off(sTa.b, oh), hb1 = ld_off(sHur.b, oh), ha0 = 0, ha1 = 0, lb0 = 0, lb1 = 0, la0 = 0, la1 = 0;
+            if (LERP) { ha0 = ld_off(sTa.a, oh); ha1 = ld_off(sHur.a, oh); }
+            if (!seq) {
+                const O o = off_of(i1);
+                lb0 = ld_off(sTa.b, o); lb1 = ld_off(sHur.b, o);
+                if (LERP) { la0 = ld_off(sTa.a, o); la1 = ld_off(sHur.a, o); }
+            }
+            if (seq) { a_lo = a_hi; b_lo = b_hi; }
+            else { a_lo = is_sfc(i1) ? sfa : tl(sTa, lb0, la0); b_lo = is_sfc(i1) ? sfb : tl(sHur, lb1, la1); }
+            a_hi = is_sfc(ih) ? sfa : tl(sTa, hb0, ha0);
+            b_hi = is_sfc(ih) ? sfb : tl(sHur, hb1, ha1);
             ci1 = i1;
         };
         auto fetch2 = [&](int i1) {
             if (ci2 == i1) return;
-            O o = dbase + (O)(S - 1 - i1) * row;
-            if (ci2 + 1 == i1) { c_lo = c_hi; d_lo = d_hi; }
-            else { c_lo = sUa.template get_at<LERP, REF>(o, by_x_hi); d_lo = sVa.template get_at<LERP, REF>(o, by_x_hi); }
-            int ih = (i1 + 1 < S) ? i1 + 1 : i1;
-            O oh = dbase + (O)(S - 1 - ih) * row;
-            c_hi = sUa.template get_at<LERP, REF>(oh, by_x_hi);
-            d_hi = sVa.template get_at<LERP, REF>(oh, by_x_hi);
+            const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+            const O oh = off_of(ih);
+            const bool seq = (ci2 + 1 == i1);
+            T hb0 = ld_off(sUa.b, oh), hb1 = ld_off(sVa.b, oh), ha0 = 0, ha1 = 0, lb0 = 0, lb1 = 0, la0 = 0, la1 = 0;
+            if (LERP) { ha0 = ld_off(sUa.a, oh); ha1 = ld_off(sVa.a, oh); }
+            if (!seq) {
+                const O o = off_of(i1);
+                lb0 = ld_off(sUa.b, o); lb1 = ld_off(sVa.b, o);
+                if (LERP) { la0 = ld_off(sUa.a, o); la1 = ld_off(sVa.a, o); }
+            }
+            if (seq) { c_lo = c_hi; d_lo = d_hi; }
+            else { c_lo = tl(sUa, lb0, la0); d_lo = tl(sVa, lb1, la1); }
+            c_hi = tl(sUa, hb0, ha0);
+            d_hi = tl(sVa, hb1, ha1);
             ci2 = i1;
+        };
+        // both axes step to the same bracket (they coincide above the surface insertion): the records of all four
+        // variables in one batch
+        auto fetch12 = [&](int i1) {
+            if (!(ci1 + 1 == i1 && ci2 + 1 == i1)) { fetch2(i1); fetch1(i1); return; }
+            const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+            const O oh = off_of(ih);
+            T b0 = ld_off(sTa.b, oh), b1 = ld_off(sHur.b, oh), b2 = ld_off(sUa.b, oh), b3 = ld_off(sVa.b, oh);
+            T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            if (LERP) { a0 = ld_off(sTa.a, oh); a1 = ld_off(sHur.a, oh); a2 = ld_off(sUa.a, oh); a3 = ld_off(sVa.a, oh); }
+            a_lo = a_hi; b_lo = b_hi; c_lo = c_hi; d_lo = d_hi;
+            a_hi = is_sfc(ih) ? sfa : tl(sTa, b0, a0);
+            b_hi = is_sfc(ih) ? sfb : tl(sHur, b1, a1);
+            c_hi = tl(sUa, b2, a2);
+            d_hi = tl(sVa, b3, a3);
+            ci1 = ci2 = i1;
         };
         int j1 = 0, j2 = 0;
         double xprev = -__builtin_inf();
@@ -1155,7 +1195,8 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         else if (j2 == 0) { p1 = p2 = 0; }                         // below range, constant :534-536
                         else { p1 = j2 - 1; p2 = j2; }                             // bracket               :545-548
                     }
-                    fetch2(p1);
+                    const bool same_axis = (ksfc < 0 || j2 < ksfc);       // ta / hur stand at the same bracket (see below)
+                    if (same_axis) fetch12(p1); else fetch2(p1);
                     dc = c_lo; dd = d_lo;
                     double dxp = 0.0;
                     SharedDivisor by_Dp(1.0, 1.0);
@@ -1170,8 +1211,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                     // Source levels below index ksfc are untouched, so while the plain scan stands at j2 < ksfc the
                     // modified scan stands there too (same values, same rule): same bracket, same x - x1, same divisor.
                     double da, db;
-                    if (ksfc < 0 || j2 < ksfc) {
-                        fetch1(p1);
+                    if (same_axis) {
                         da = a_lo; db = b_lo;
                         if (p1 != p2) {
                             da = a_lo + by_Dp.divide(dxp * ydiff(a_hi, a_lo));

@@ -55,7 +55,7 @@ def trace_stats():
             n = len(dur)
             drop = n * W // (W + K) if (n % (W + K) == 0 and n >= W + K) else (1 if n > 1 else 0)
             t = dur[drop:]
-            rows.append((sum(dur), '%s,%d,%.1f,%.1f,%.1f,%.3f,%d,%.1f,%.1f,%.1f,%.1f\n' % (
+            rows.append((sum(dur), '"%s",%d,%.1f,%.1f,%.1f,%.3f,%d,%.1f,%.1f,%.1f,%.1f\n' % (
                 k, n, sum(dur) / n, min(dur), max(dur), sum(dur) / 1e3, len(t), sum(t) / len(t), statistics.median(t), min(t), max(t))))
         for _, line in sorted(rows, reverse=True):
             o.write(line)
