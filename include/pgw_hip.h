@@ -61,7 +61,7 @@ enum pgw_kernel_id {
     PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
     PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
     PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13, PGW_K_QUAD_DELTA = 14,
-    PGW_K_BYTESWAP = 15, PGW_K_HARMONIC = 16, PGW_K_COUNT = 17
+    PGW_K_BYTESWAP = 15, PGW_K_HARMONIC = 16, PGW_K_GAUSS_INTERP = 17, PGW_K_COUNT = 18
 };
 
 /* per-context options (pgw_set_option).  Defaults come from the environment variables named below, which are read
@@ -330,6 +330,19 @@ int pgw_surface_update(pgw_ctx *ctx, int dtype, int ntime, long long ncol, int n
  * message (:734-737); ntime <= 1365. */
 int pgw_harmonic_smooth(pgw_ctx *ctx, int dtype, int ntime, long long inner, const double *cos_tab,
                         const double *sin_tab, const void *in, void *out);
+
+/* NaN-ignoring Gaussian-kernel interpolation of a point cloud onto target points, step_02 for tos / siconc:
+ * nan_ignoring_interp, functions.py:900-1060 (pyvista PolyData.interpolate = VTK vtkPointInterpolator + vtkGaussianKernel,
+ * radius footprint, null value NaN).  All pointers are DEVICE pointers, coordinates planar metres (functions.py:958-1023;
+ * host side: pgw4era5_amd/geodesy.py).
+ *  tx, ty (ntarg): target points.  sx, sy (nsrc), sval (nsrc, nfield): source points SORTED by cell of a uniform grid of
+ *  square cells (edge `cell` >= radius, origin (x0, y0), ncx x ncy cells, cell id = ix * ncy + iy), `cell_start`
+ *  (ncx*ncy + 1 ints): first point of each cell.  sval may hold NaN: that point is skipped for that field (month).
+ *  out (nfield, ntarg): sum_i w_i v_i / sum_i w_i, w_i = exp(-(sharpness/radius)^2 d_i^2) over the points with
+ *  d_i <= radius; the value of a coincident point (d^2 < 256 eps); NaN where no point lies within the radius. */
+int pgw_gauss_interp(pgw_ctx *ctx, long long ntarg, const double *tx, const double *ty, int ncx, int ncy,
+                     double x0, double y0, double cell, const int *cell_start, long long nsrc, const double *sx,
+                     const double *sy, const double *sval, int nfield, double radius, double sharpness, double *out);
 
 /* Byte-order conversion on the device: dst[i] = byte-reversed src[i] for n elements of 4 or 8 bytes (in place
  * allowed).  NetCDF classic files are big-endian (the reference reads / writes them through xarray,

@@ -826,3 +826,105 @@ def filter_data_array(diff):
     for c in range(flat.shape[1]):
         flat[:, c] = harmonic_ac_analysis(flat[:, c])
     return flat.reshape(diff.shape)
+
+
+# =====================================================================================
+# step_02 NaN-ignoring interpolation of ocean-grid deltas (tos, siconc)      functions.py:900-1060
+# PARITY UNPINNED: the arithmetic lives in third-party code that is not in /root/reference and not installable here -
+# pyproj 3.4.0 `Geod(ellps="WGS84").inv` (Karney's geodesic inverse; environment.yml:198-203) and pyvista 0.37.0
+# `PolyData.interpolate` = VTK 9.2.2 vtkPointInterpolator + vtkGaussianKernel.  Restated from their published
+# algorithms: geodesic lengths by Vincenty's inverse iteration (Survey Review 1975; agrees with Karney's to < 0.1 mm
+# where it converges - it does not for nearly antipodal points, which this oracle refuses), the kernel from
+# vtkGaussianKernel::ComputeWeights (w = exp(-(sharpness/radius)^2 d^2) over the points within the radius,
+# normalised; a coincident point, d^2 < 256 eps, takes all the weight; no point -> null value).
+# =====================================================================================
+WGS84_A = 6378137.0
+WGS84_F = 1.0 / 298.257223563
+
+
+def geod_inv_distance(lon1, lat1, lon2, lat2):
+    """Third return value of pyproj Geod(ellps='WGS84').inv(lon1, lat1, lon2, lat2): geodesic length [m].
+    Scalar Vincenty inverse iteration; exactly antipodal-in-longitude points of equal latitude (the reference's
+    lon_offset call, functions.py:969) go over the pole along the meridians."""
+    import math
+    a, f = WGS84_A, WGS84_F
+    b = a * (1 - f)
+    if lat1 == lat2 and lon1 == lon2:
+        return 0.0
+    dl = abs(lon2 - lon1) % 360.0
+    dl = 360.0 - dl if dl > 180.0 else dl
+    if lat1 == lat2 and dl == 180.0:                       # meridians over the nearer pole
+        return 2.0 * (geod_inv_distance(0.0, 0.0, 0.0, 90.0) - geod_inv_distance(0.0, 0.0, 0.0, abs(lat1)))
+    U1 = math.atan((1 - f) * math.tan(math.radians(lat1))) if abs(lat1) < 90 else math.copysign(math.pi / 2, lat1)
+    U2 = math.atan((1 - f) * math.tan(math.radians(lat2))) if abs(lat2) < 90 else math.copysign(math.pi / 2, lat2)
+    L = math.radians(dl)
+    lam = L
+    for _ in range(500):
+        sl, cl = math.sin(lam), math.cos(lam)
+        ss = math.sqrt((math.cos(U2) * sl) ** 2 + (math.cos(U1) * math.sin(U2) - math.sin(U1) * math.cos(U2) * cl) ** 2)
+        if ss == 0.0:
+            return 0.0
+        cs = math.sin(U1) * math.sin(U2) + math.cos(U1) * math.cos(U2) * cl
+        sig = math.atan2(ss, cs)
+        sa = math.cos(U1) * math.cos(U2) * sl / ss
+        c2a = 1 - sa * sa
+        c2sm = cs - 2 * math.sin(U1) * math.sin(U2) / c2a if c2a > 1e-300 else 0.0
+        C = f / 16 * c2a * (4 + f * (4 - 3 * c2a))
+        new = L + (1 - C) * f * sa * (sig + C * ss * (c2sm + C * cs * (-1 + 2 * c2sm * c2sm)))
+        if abs(new - lam) < 1e-15:
+            lam = new
+            break
+        lam = new
+    else:
+        raise ValueError('Vincenty inverse did not converge (nearly antipodal points): outside this oracle')
+    u2 = c2a * (a * a - b * b) / (b * b)
+    A = 1 + u2 / 16384 * (4096 + u2 * (-768 + u2 * (320 - 175 * u2)))
+    B = u2 / 1024 * (256 + u2 * (-128 + u2 * (74 - 47 * u2)))
+    ds = B * ss * (c2sm + B / 4 * (cs * (-1 + 2 * c2sm ** 2) - B / 6 * c2sm * (-3 + 4 * ss ** 2) * (-3 + 4 * c2sm ** 2)))
+    return b * A * (sig - ds)
+
+
+def planar_metres(lat, lon):
+    """functions.py:958-975: (lat_m, lon_m, lon_offset) of points with lon already in (-180, 180]."""
+    lat = np.asarray(lat, dtype=np.float64); lon = np.asarray(lon, dtype=np.float64)
+    lat_m = np.array([geod_inv_distance(lo, 0.0, lo, la) for la, lo in zip(lat, lon)]) * np.sign(lat)         # :966
+    lon_m = np.array([geod_inv_distance(0.0, la, lo, la) for la, lo in zip(lat, lon)]) * np.sign(lon)         # :967
+    off = np.array([geod_inv_distance(0.0, la, 180.0, la) for la in lat])                                      # :968
+    return lat_m, lon_m, off
+
+
+def nan_ignoring_interp(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, values, kernel_radius, sharpness):
+    """functions.py:900-1060 on plain arrays: land_fr (nlat, nlon), era5_lat (nlat), era5_lon (nlon); gcm_lat, gcm_lon,
+    values of one common shape.  Brute force over all pairs (small cases)."""
+    glat = np.asarray(gcm_lat, dtype=np.float64).reshape(-1)
+    glon = np.array(gcm_lon, dtype=np.float64).reshape(-1)
+    val = np.asarray(values, dtype=np.float64).reshape(-1)
+    glon[glon > 180] -= 360                                                     # :938-941
+    ok = ~np.isnan(val)                                                         # :944-948
+    val, glon, glat = val[ok], glon[ok], glat[ok]
+    lat_m, lon_m, off = planar_metres(glat, glon)
+    sx = np.tile(lat_m, 3)                                                      # :977-991
+    sy = np.concatenate([lon_m - 2 * off, lon_m, lon_m + 2 * off])
+    sv = np.tile(val, 3)
+    elat = np.asarray(era5_lat, dtype=np.float64)
+    elon = np.array(era5_lon, dtype=np.float64)
+    elon[elon > 180] -= 360                                                     # :998-1001
+    tlat = np.repeat(elat, len(elon)); tlon = np.tile(elon, len(elat))          # :1004-1005
+    tx, ty, _ = planar_metres(tlat, tlon)
+    f2 = (sharpness / kernel_radius) ** 2                                       # vtkGaussianKernel: F2 = Sharpness^2 / Radius^2
+    r2 = kernel_radius ** 2
+    out = np.full(len(tx), np.nan)                                              # null_value = nan, :1041
+    tol = 256.0 * np.finfo(np.float64).eps
+    for i in range(len(tx)):
+        d2 = (tx[i] - sx) ** 2 + (ty[i] - sy) ** 2
+        m = d2 <= r2                                                            # FindPointsWithinRadius
+        if not m.any():
+            continue
+        hit = np.nonzero(m & (d2 < tol))[0]
+        if len(hit):
+            out[i] = sv[hit[0]]
+            continue
+        w = np.exp(-f2 * d2[m])
+        out[i] = np.sum(w / w.sum() * sv[m])                                    # NormalizeWeights, then sum w_i v_i
+    out[np.asarray(land_fr, dtype=np.float64).reshape(-1) > 0.7] = np.nan       # :1032, 1055
+    return out.reshape(len(elat), len(elon))

@@ -23,7 +23,7 @@ PGW_F32, PGW_F64 = 0, 1
 EXTRAP = {'off': 0, 'linear': 1, 'constant': 2, 'nan': 3}
 KERNEL_IDS = dict(pressure=0, q_to_rh=1, rh_to_q=2, integ_geopot=3, interp_logp=4, time_lerp=5,
                   vert_interp_delta=6, adjust_ps_step=7, regrid=8, surface=9, finalize=10,
-                  thermo_delta=11, wind_delta=12, phi_ref_hybrid=13, quad_delta=14, byteswap=15, harmonic=16)
+                  thermo_delta=11, wind_delta=12, phi_ref_hybrid=13, quad_delta=14, byteswap=15, harmonic=16, gauss_interp=17)
 
 # enum pgw_option (include/pgw_hip.h)
 OPTIONS = dict(quad=0, full_column=1, force_vec1=2, multipass=3)
@@ -117,6 +117,7 @@ SIGNATURES['pgw_test_exp'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_test_shared_div'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_byteswap'] = (_i, [_vp, _i, _ll, _vp, _vp])
 SIGNATURES['pgw_harmonic_smooth'] = (_i, [_vp, _i, _i, _ll, _dp, _dp, _vp, _vp])
+SIGNATURES['pgw_gauss_interp'] = (_i, [_vp, _ll, _vp, _vp, _i, _i, _d, _d, _d, _vp, _ll, _vp, _vp, _vp, _i, _d, _d, _vp])
 
 _lib = None
 

@@ -1124,6 +1124,25 @@ extern "C" int pgw_harmonic_smooth(pgw_ctx *ctx, int dtype, int ntime, long long
     return PGW_OK;
 }
 
+extern "C" int pgw_gauss_interp(pgw_ctx *ctx, long long ntarg, const double *tx, const double *ty, int ncx, int ncy,
+                                double x0, double y0, double cell, const int *cell_start, long long nsrc, const double *sx,
+                                const double *sy, const double *sval, int nfield, double radius, double sharpness, double *out) {
+    NEED(ctx, ntarg >= 1 && nsrc >= 0 && tx && ty && cell_start && out, "bad argument");
+    NEED(ctx, nsrc == 0 || (sx && sy && sval), "null source pointer");
+    NEED(ctx, ncx >= 1 && ncy >= 1 && cell > 0.0 && radius > 0.0, "bad cell grid");
+    NEED(ctx, cell >= radius, "cells must be at least one kernel radius wide (3 x 3 block search)");
+    NEED(ctx, nfield >= 1 && nfield <= GAUSS_MAX_FIELDS, "nfield must be in [1, 16]");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double r2 = radius * radius, f2 = (sharpness * sharpness) / (radius * radius);     // vtkGaussianKernel: F2 = (Sharpness / Radius)^2
+    {
+        Prof pr(ctx, PGW_K_GAUSS_INTERP);
+        hipLaunchKernelGGL((k_gauss_interp<GAUSS_MAX_FIELDS>), dim3(nblocks(ntarg, BLOCK)), dim3(BLOCK), 0, ctx->stream, ntarg, tx, ty,
+                           ncx, ncy, x0, y0, 1.0 / cell, cell_start, sx, sy, sval, nfield, r2, f2, out);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst) {
     NEED(ctx, elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 or 8");
     NEED(ctx, n >= 0 && (n == 0 || (src && dst)), "bad argument");

@@ -1702,6 +1702,75 @@ __global__ __launch_bounds__(BLOCK) void k_harmonic_smooth(int ntime, long long 
     }
 }
 
+// =====================================================================================
+// step_02 NaN-ignoring interpolation of ocean-grid deltas (tos, siconc)      functions.py:900-1060
+// The reference hands two point clouds in planar "metre" coordinates (functions.py:958-1023; host: geodesy.py) to
+// pyvista's PolyData.interpolate(points, null_value=nan, radius=R, sharpness=s) (:1038-1048) = VTK's vtkPointInterpolator
+// with a vtkGaussianKernel on a RADIUS footprint.  Per target point x (VTK 9.2 vtkGaussianKernel::ComputeWeights,
+// vtkPointInterpolator):
+//     neighbours  = source points with |x - p|^2 <= R^2 ;  none -> null value (NaN)
+//     |x - p|^2 < 256 eps for some p  ->  the value of (the first such) p
+//     else  sum_i w_i v_i / sum_i w_i ,  w_i = exp(-(s/R)^2 |x - p_i|^2)
+// (VTK divides the weights by their sum first and then forms sum (w_i / W) v_i; here the quotient of the two sums is
+// taken once - equal up to rounding; parity with VTK is unpinned anyway: VTK / pyvista / pyproj are not installable.)
+// Source points are binned on the host into square cells of edge R (sorted by cell, `cell_start` = first point of each
+// cell), so a target looks at its 3 x 3 block of cells.  One thread per target point; all `nm` months of a variable in
+// ONE pass (the geometry - the expensive part, one exp per pair - is shared; the reference repeats it 12 times).  A
+// month's NaN values are skipped for that month (the reference removes them from that month's cloud, :944-948).
+// =====================================================================================
+constexpr int GAUSS_MAX_FIELDS = 16;
+template <int NM>
+__global__ __launch_bounds__(BLOCK) void k_gauss_interp(long long ntarg, const double *__restrict__ tx, const double *__restrict__ ty,
+                                                        int ncx, int ncy, double x0, double y0, double inv_h,
+                                                        const int *__restrict__ cell_start, const double *__restrict__ sx,
+                                                        const double *__restrict__ sy, const double *__restrict__ sval /* [nsrc][nm] */,
+                                                        int nm, double r2, double f2, double *__restrict__ out /* [nm][ntarg] */) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= ntarg) return;
+    const double x = tx[i], y = ty[i];
+    double sw[NM], swv[NM], hit[NM];
+    bool has_hit[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { sw[m] = 0.0; swv[m] = 0.0; hit[m] = 0.0; has_hit[m] = false; }
+    const int cx = (int)floor((x - x0) * inv_h), cy = (int)floor((y - y0) * inv_h);
+    const double tol = 256.0 * 2.220446049250313e-16;           // vtkMathUtilities::FuzzyCompare(d2, 0.0, eps * 256)
+    for (int ix = cx - 1; ix <= cx + 1; ++ix) {
+        if (ix < 0 || ix >= ncx) continue;
+        for (int iy = cy - 1; iy <= cy + 1; ++iy) {
+            if (iy < 0 || iy >= ncy) continue;
+            const int c = ix * ncy + iy;
+            const int p0 = cell_start[c], p1 = cell_start[c + 1];
+            for (int p = p0; p < p1; ++p) {
+                const double dx = x - sx[p], dy = y - sy[p];
+                const double d2 = dx * dx + dy * dy;             // the third coordinate is 0 on both sides (:986-988, 1028-1030)
+                if (!(d2 <= r2)) continue;                       // vtkStaticPointLocator::FindPointsWithinRadius
+                const double w = pgw_exp(-f2 * d2);
+                const bool exact = d2 < tol;
+                const double *v = sval + (long long)p * nm;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    if (m < nm) {
+                        const double vm = v[m];
+                        if (vm == vm) {
+                            sw[m] += w; swv[m] += w * vm;
+                            if (exact && !has_hit[m]) { has_hit[m] = true; hit[m] = vm; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        if (m < nm) {
+            double r = __builtin_nan("");                        // null_value (:1041)
+            if (has_hit[m]) r = hit[m];
+            else if (sw[m] > 0.0) r = swv[m] / sw[m];
+            out[(long long)m * ntarg + i] = r;
+        }
+    }
+}
+
 // Byte-order conversion of a field (NetCDF classic data are big-endian): every 4- or 8-byte element of `src` is
 // written byte-reversed to `dst` (in place allowed), 16 B per lane, grid-stride.  HBM-bound: 2 x n x W bytes.
 template <int W>

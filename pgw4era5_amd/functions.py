@@ -24,7 +24,7 @@ from .device import DeviceArray, default_context, dtype_tag, ptr
 from .settings import (                      # noqa: F401
     i_debug, i_use_xesmf_regridding, file_name_bases,
     TIME_ERA, LEV_ERA, HLEV_ERA, LON_ERA, LAT_ERA,
-    TIME_GCM, PLEV_GCM, LON_GCM, LAT_GCM,
+    TIME_GCM, PLEV_GCM, LON_GCM, LAT_GCM, LON_GCM_OCEAN, LAT_GCM_OCEAN,
 )
 
 _dp = C.POINTER(C.c_double)
@@ -605,13 +605,129 @@ def filter_data(annualcycleraw, variablename_to_smooth, outputpath):
     ncio.to_netcdf(out, outputpath)
 
 
+# ------------------------------------------------------------------------------- step_02: ocean-grid deltas
+def _fold_lon(lon):
+    """functions.py:938-941 / 998-1001: longitudes above 180 move to the (-180, 180] range."""
+    lon = np.array(lon, dtype=np.float64, copy=True)
+    lon[lon > 180] -= 360
+    return lon
+
+
+def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, kernel_radius, sharpness):
+    """The geometry and the GPU pass of nan_ignoring_interp for SEVERAL fields on the same source points (the twelve
+    months of a variable: interp_wrapper calls nan_ignoring_interp once per month, functions.py:1102-1109, rebuilding
+    the same two point clouds each time).
+    land_fr (nlat, nlon); era5_lat (nlat), era5_lon (nlon); gcm_lat, gcm_lon, fields[k]: arrays of one common shape
+    (curvilinear 2-D coordinates flattened like :931-933).  Returns (nfield, nlat, nlon) float64."""
+    from . import geodesy
+    ctx = default_context()
+    vals = np.stack([np.asarray(f, dtype=np.float64).reshape(-1) for f in fields], axis=1)       # (npoint, nfield)
+    glat = np.asarray(gcm_lat, dtype=np.float64).reshape(-1)
+    glon = _fold_lon(np.asarray(gcm_lon).reshape(-1))
+    if not (glat.shape == glon.shape == vals.shape[:1]):
+        raise ValueError('ocean-grid coordinates and values must have the same number of points')
+    nf = vals.shape[1]
+    keep = ~np.isnan(vals).all(axis=1)                         # :944-948 (a point that is NaN in every field is in no cloud)
+    glat, glon, vals = glat[keep], glon[keep], vals[keep]
+    lat_m, lon_m, lon_off = geodesy.planar_metres(glat, glon)                                   # :958-975
+    # :977-991 the whole field once more to the left and to the right, shifted by twice the half-way-round length
+    sx = np.tile(lat_m, 3)
+    sy = np.concatenate([lon_m - 2 * lon_off, lon_m, lon_m + 2 * lon_off])
+    sv = np.tile(vals, (3, 1))
+    elat = np.asarray(era5_lat, dtype=np.float64)
+    elon = _fold_lon(era5_lon)
+    tlat = np.repeat(elat, len(elon)); tlon = np.tile(elon, len(elat))                         # :1004-1005
+    # lat_m depends on the latitude only, lon_m on (|lat|, |lon|): evaluate the distinct values of the regular grid once
+    la_u, la_i = np.unique(np.abs(elat), return_inverse=True)
+    lo_u, lo_i = np.unique(np.abs(elon), return_inverse=True)
+    lat_arc = geodesy.meridian_arc(la_u)
+    lon_arc = geodesy.same_latitude_geodesic(la_u[:, None], lo_u[None, :])
+    tx = (lat_arc[la_i] * np.sign(elat))[:, None] * np.ones(len(elon))[None, :]
+    ty = lon_arc[np.ix_(la_i, lo_i)] * np.sign(elon)[None, :]
+    tx, ty = np.ascontiguousarray(tx.reshape(-1)), np.ascontiguousarray(ty.reshape(-1))
+    # uniform cells of one kernel radius over the source cloud
+    h = float(kernel_radius)
+    if len(sx):
+        x0, y0 = float(sx.min()), float(sy.min())
+        ncx, ncy = int((sx.max() - x0) // h) + 1, int((sy.max() - y0) // h) + 1
+        cid = ((sx - x0) // h).astype(np.int64) * ncy + ((sy - y0) // h).astype(np.int64)
+        order = np.argsort(cid, kind='stable')
+        sx, sy, sv, cid = sx[order], sy[order], sv[order], cid[order]
+        cell_start = np.searchsorted(cid, np.arange(ncx * ncy + 1)).astype(np.int32)
+    else:
+        x0 = y0 = 0.0; ncx = ncy = 1
+        cell_start = np.zeros(2, dtype=np.int32)
+    f64 = np.dtype('float64')
+    d_tx, d_ty = ctx.to_device(tx, f64), ctx.to_device(ty, f64)
+    d_sx, d_sy = ctx.to_device(sx if len(sx) else np.zeros(1), f64), ctx.to_device(sy if len(sy) else np.zeros(1), f64)
+    d_sv = ctx.to_device(np.ascontiguousarray(sv) if len(sx) else np.zeros((1, nf)), f64)
+    d_cs = ctx.empty(cell_start.shape, np.int32).copy_from(cell_start)
+    ntarg = len(tx)
+    out = np.empty((nf, ntarg))
+    for k0 in range(0, nf, 16):                               # the kernel takes up to 16 fields per pass
+        k1 = min(k0 + 16, nf)
+        if k0 or k1 < nf:
+            d_sub = ctx.to_device(np.ascontiguousarray(sv[:, k0:k1]), f64)
+        else:
+            d_sub = d_sv
+        d_out = ctx.empty((k1 - k0, ntarg), f64)
+        ctx._check(ctx.lib.pgw_gauss_interp(ctx.handle, ntarg, d_tx.ptr, d_ty.ptr, ncx, ncy, x0, y0, h, d_cs.ptr, len(sx),
+                                            d_sx.ptr, d_sy.ptr, d_sub.ptr, k1 - k0, float(kernel_radius), float(sharpness), d_out.ptr))
+        out[k0:k1] = d_out.numpy()
+    land = np.asarray(land_fr, dtype=np.float64).reshape(-1)
+    out[:, land > 0.7] = np.nan                               # :1032, 1055: no SST on land points
+    return out.reshape(nf, len(elat), len(elon))
+
+
+def _ocean_coords(da_delta):
+    """Latitudes / longitudes of the ocean grid as arrays of the values' shape (functions.py:920-933).  The reference
+    builds a meshgrid for 1-D coordinates and then overwrites it with the raw 1-D coordinates (:931-932), which cannot
+    index the flattened values; the meshgrid (evidently intended) is used here."""
+    lat = np.asarray(da_delta.coords[LAT_GCM_OCEAN])
+    lon = np.asarray(da_delta.coords[LON_GCM_OCEAN])
+    if lat.ndim == 2:
+        return lat, lon
+    if lat.ndim == 1:
+        return np.meshgrid(lat, lon, indexing='ij')
+    raise NotImplementedError()
+
+
+def nan_ignoring_interp(da_era5_land_fr, da_delta, kernel_radius, sharpness):
+    """Point-cloud interpolation of a 2-D ocean-grid field onto the ERA5 grid, ignoring NaN source points; land points
+    (FR_LAND > 0.7) come back NaN.  reference functions.py:900-1060.  Labelled inputs like the reference's
+    (`.values`, `.coords` with the ocean grid's `latitude` / `longitude`, ERA5 `lat` / `lon`)."""
+    glat, glon = _ocean_coords(da_delta)
+    res = gauss_interp_fields(np.asarray(da_era5_land_fr.values), da_era5_land_fr.coords[LAT_ERA], da_era5_land_fr.coords[LON_ERA],
+                              glat, glon, [np.asarray(da_delta.values)], kernel_radius, sharpness)
+    return res[0]
+
+
 def interp_wrapper(origin_grid, target_grid, var_name, i_use_xesmf=0,
                    nan_interp_kernel_radius=300000, nan_interp_sharpness=3):
     """Per-variable choice of the regridding scheme (reference functions.py:1062-1141).
-    Atmospheric variables: bilinear on the GPU.  `tos` / `siconc` use the reference's
-    pyvista/VTK point-cloud interpolation (functions.py:900-1060), which is outside this build
-    (SURVEY.md section 2 / 8 f rank 4)."""
+    Atmospheric variables: bilinear on the GPU.  `tos` / `siconc` (ocean grid, NaN over land): the Gaussian-kernel
+    point-cloud interpolation, all twelve months in one pass."""
+    from . import ncio
     if var_name in ['tos', 'siconc']:
-        raise NotImplementedError('NaN-ignoring ocean-grid interpolation (functions.py:900-1060, pyvista/VTK) '
-                                  'is out of scope of the MI355X hot path; run the reference for %s' % var_name)
+        land = target_grid['FR_LAND']
+        land2d = np.asarray(land.values)[0]                                        # target_grid["FR_LAND"][0,:,:]  :1097
+        values = origin_grid[var_name]
+        glat, glon = _ocean_coords(ncio.Field(values.values[0], values.dims[1:],
+                                              {LAT_GCM_OCEAN: np.asarray(origin_grid[LAT_GCM_OCEAN].values),
+                                               LON_GCM_OCEAN: np.asarray(origin_grid[LON_GCM_OCEAN].values)}))
+        if values.shape[0] != 12:
+            raise ValueError('could not broadcast input array: %s has %d time steps, the ocean-grid interpolation expects 12 months'
+                             % (var_name, values.shape[0]))                         # result = np.empty((12, ...))  :1101
+        tlat = np.asarray(target_grid[LAT_ERA].values, dtype=np.float64)
+        tlon = np.asarray(target_grid[LON_ERA].values, dtype=np.float64)
+        result = gauss_interp_fields(land2d, tlat, tlon, glat, glon, [values.values[i] for i in range(12)],
+                                     nan_interp_kernel_radius, nan_interp_sharpness)
+        ds = ncio.Dataset(attrs=dict(description=str(var_name) + " on ERA5 grid", units="K", long_name=str(var_name)))   # :1121, 1134
+        ds['lat'] = ncio.Field(tlat, ('lat',), {'lat': tlat}, target_grid[LAT_ERA].attrs)
+        ds['lon'] = ncio.Field(tlon, ('lon',), {'lon': tlon}, target_grid[LON_ERA].attrs)
+        t = origin_grid[TIME_GCM]
+        ds['time'] = ncio.Field(t.values, ('time',), {'time': t.values}, {k: v for k, v in t.attrs.items() if k not in ('units', 'calendar')}
+                                if t.values.dtype.kind == 'M' else t.attrs)
+        ds[var_name] = ncio.Field(result, ('time', 'lat', 'lon'), {'time': t.values, 'lat': tlat, 'lon': tlon})
+        return ds
     return regrid_lat_lon(origin_grid, target_grid, var_name, method='bilinear', i_use_xesmf=i_use_xesmf)

@@ -5,8 +5,8 @@ Command line of the reference's step_02_preproc_deltas.py (:27-87): positional
 {smoothing,regridding}, -i, -o, -e, -v.  For every variable both `{var}_historical.nc` and
 `{var}_delta.nc` are processed (:116-119).  `regridding` runs the bilinear lat-then-lon kernel
 (functions.regrid_lat_lon); `smoothing` runs the annual-cycle filter for daily deltas
-(functions.filter_data, reference functions.py:603-740); the tos/siconc point-cloud interpolation
-is outside this build.
+(functions.filter_data, reference functions.py:603-740); tos / siconc on the ocean grid go through the
+NaN-ignoring Gaussian-kernel interpolation (functions.nan_ignoring_interp, reference functions.py:900-1060).
 """
 import argparse
 import os
@@ -49,8 +49,6 @@ def main(argv=None):
                 filter_data(inp, var_name, out)
                 done.append(out)
             continue
-        if var_name in ('tos', 'siconc'):
-            interp_wrapper(None, ds_era5, var_name)      # raises: ocean-grid scheme is out of scope
         for clim_period in ['HIST', 'SCEN-HIST']:
             fname = file_name_bases[clim_period].format(var_name)
             inp, out = os.path.join(args.input_dir, fname), os.path.join(args.output_dir, fname)

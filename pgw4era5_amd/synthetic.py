@@ -173,6 +173,34 @@ def make_gcm_grid_case(nlat_src=48, nlon_src=96, nlat=37, nlon=72, nplev=5, ntim
     return dict(field=f, src_lat=src_lat, src_lon=src_lon, targ_lat=targ_lat, targ_lon=targ_lon)
 
 
+def make_ocean_grid_case(nj=40, ni=60, ntime=12, seed=0, land_patches=3):
+    """An ocean-model-like delta for step_02's NaN-ignoring interpolation (tos / siconc): curvilinear grid with 2-D
+    `latitude` / `longitude` coordinates (a regular grid sheared and stretched so that rows are not parallels, longitudes
+    0 ... 360 like CMIP ocean output), values smooth in space, NaN over a few "continents".
+    Returns dict(latitude (nj, ni), longitude (nj, ni), values (ntime, nj, ni), times)."""
+    rng = np.random.default_rng(seed)
+    j = (np.arange(nj) + 0.5) / nj
+    i = (np.arange(ni) + 0.5) / ni
+    lat0 = -78.0 + 166.0 * j                                   # -78 ... 88: no ocean points at the south pole
+    lon0 = 360.0 * i
+    lat2 = lat0[:, None] + 3.0 * np.sin(2 * np.pi * i)[None, :] * np.cos(np.deg2rad(lat0))[:, None]
+    lon2 = (lon0[None, :] + 8.0 * (j[:, None] - 0.5) ** 2 * 4.0) % 360.0
+    lat2 = np.clip(lat2, -89.5, 89.5)
+    base = 1.5 + np.cos(np.deg2rad(lat2)) * (1.0 + 0.3 * np.sin(np.deg2rad(2 * lon2)))
+    season = 1.0 + 0.2 * np.cos(2 * np.pi * (np.arange(ntime) - 0.5) / max(ntime, 1))
+    vals = season[:, None, None] * base[None]
+    land = np.zeros((nj, ni), dtype=bool)
+    for _ in range(land_patches):
+        cj, ci = rng.integers(nj // 6, 5 * nj // 6), rng.integers(0, ni)
+        rj, ri = rng.integers(2, max(nj // 6, 3)), rng.integers(2, max(ni // 6, 3))
+        jj, ii = np.ogrid[:nj, :ni]
+        di = np.minimum(np.abs(ii - ci), ni - np.abs(ii - ci))
+        land |= ((jj - cj) / rj) ** 2 + (di / ri) ** 2 <= 1.0
+    vals = np.where(land[None], np.nan, vals)
+    times = np.array(['1995-%02d-15T12:00:00' % (m % 12 + 1) for m in range(ntime)], dtype='datetime64[s]')
+    return dict(latitude=lat2, longitude=lon2, values=vals, times=times, land=land)
+
+
 def write_case_files(case, era_dir, delta_dir, era_name=None):
     """Write a make_case() result as the NetCDF-3 files the step_03 driver reads: one ERA5 file
     (reference file schema) and the delta directory ({var}_delta.nc,
