@@ -112,6 +112,11 @@ def kernel_bytes(name, N, S, ncol, s, info):
     if name == 'adjust_ps_step':      # ta_pgw, e per level read; PS,FIS (storage) + 6 fp64 state words
         lv = info.get('levels_per_launch', N * ncol)
         return 2 * lv * so + ncol * (2 * s + 6 * 8)
+    if name == 'ps_loop_multi':       # first launch of a file: T, QV of the ERA state below p_ref + passes_per_launch passes,
+        # each re-reading ta_pgw, e below p_ref; PS, FIS, zg records in, 4 fp64 state words + one delta_ps per pass out
+        lv = info.get('levels_per_launch', N * ncol)
+        npass = info.get('passes_per_launch', 1.0)
+        return 2 * lv * s + npass * 2 * lv * so + ncol * (4 * s + 4 * 8 + npass * 8)
     if name == 'quad_delta':          # T, QV, U, V in; T_pgw, e, U_pgw, V_pgw out; 2 records x S for 4 variables; 8 2-D fields
         return (4 * N * s + 4 * N * so + (8 * S + 8) * s) * ncol
     if name == 'thermo_delta':        # T, QV in; T_pgw, e out; 2 records x S for ta and hur; 7 2-D fields
@@ -244,7 +249,7 @@ def main(argv=None):
         infos.append(info)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {k: ctx.profile_get(k) for k in ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'finalize',
+    prof = {k: ctx.profile_get(k) for k in ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'ps_loop_multi', 'finalize',
                                             'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q',
                                             'pressure', 'time_lerp')}
     solo = (rank == 0 and world == 1)
@@ -266,7 +271,9 @@ def main(argv=None):
             n_pure += 1
         # pure-pressure levels: their final QV is written by k_delta_quad (stop-above-p_ref passes)
         quad = not a.full_column and ctx.get_option('quad') != 0
-        kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0, so=so)
+        launches_multi = prof['ps_loop_multi'][0]
+        kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0, so=so,
+                     passes_per_launch=(sum(i.get('passes_launched', 0) for i in infos) / launches_multi) if launches_multi else 1.0)
         kern = {}
         for k, (cnt, ms) in prof.items():
             if cnt == 0:
@@ -306,6 +313,8 @@ def main(argv=None):
                        'iterations_per_file': n_iter[0] if len(set(n_iter)) == 1 else n_iter,
                        'iterations_per_file_over_ranks': [iters_min, iters_max],
                        'pass_kernel': 'full_column' if a.full_column else 'stops_above_p_ref',
+                       'passes_launched_per_file': round(sum(i.get('passes_launched', 0) for i in infos) / len(infos), 2),
+                       'loop_launches_per_file': round((prof['ps_loop_multi'][0] + prof['adjust_ps_step'][0]) / len(infos), 2),
                        'mean_levels_read_per_column_per_pass': round(lv_per_launch / ncol, 2)},
             'collective': {'backend': ('rccl (torch nccl)' if backend == 'nccl' else backend) if world > 1 else None,
                            'ranks_counted_by_all_reduce': ranks_seen,
@@ -579,7 +588,7 @@ PMC_KERNEL = {'integ_geopot': 'k_integ_geopot', 'adjust_ps_step': 'k_adjust_ps_s
               'vert_interp_delta': 'k_vert_interp_delta', 'q_to_rh': 'k_humidity_hybrid', 'rh_to_q': 'k_humidity_hybrid',
               'finalize': 'k_finalize_ps_hus', 'pressure': 'k_pressure_levels',
               'thermo_delta': 'k_delta_pair<double, 2, true>', 'wind_delta': 'k_delta_pair<double, 2, false>',
-              'phi_ref_hybrid': 'k_phi_ref_hybrid', 'quad_delta': 'k_delta_quad'}
+              'phi_ref_hybrid': 'k_phi_ref_hybrid', 'quad_delta': 'k_delta_quad', 'ps_loop_multi': 'k_ps_loop_multi'}
 
 
 def _profile_tag(a):

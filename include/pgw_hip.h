@@ -61,7 +61,8 @@ enum pgw_kernel_id {
     PGW_K_INTERP_LOGP = 4, PGW_K_TIME_LERP = 5, PGW_K_VERT_INTERP_DELTA = 6,
     PGW_K_ADJUST_PS_STEP = 7, PGW_K_REGRID = 8, PGW_K_SURFACE = 9, PGW_K_FINALIZE = 10,
     PGW_K_THERMO_DELTA = 11, PGW_K_WIND_DELTA = 12, PGW_K_PHI_REF_HYBRID = 13, PGW_K_QUAD_DELTA = 14,
-    PGW_K_BYTESWAP = 15, PGW_K_HARMONIC = 16, PGW_K_GAUSS_INTERP = 17, PGW_K_COUNT = 18
+    PGW_K_BYTESWAP = 15, PGW_K_HARMONIC = 16, PGW_K_GAUSS_INTERP = 17, PGW_K_PS_LOOP_MULTI = 18,
+    PGW_K_COUNT = 19
 };
 
 /* per-context options (pgw_set_option).  Defaults come from the environment variables named below, which are read
@@ -73,7 +74,9 @@ enum pgw_option {
     PGW_OPT_FORCE_VEC1 = 2,   /* 1: one column per thread everywhere (test knob for the scalar-column code path)  [PGW_FORCE_VEC1]  */
     PGW_OPT_MULTIPASS = 3,    /* 1 (default): several passes of the surface-pressure loop per launch with the column held
                                  on chip; 0: one launch per pass                                                 [PGW_MULTIPASS]   */
-    PGW_OPT_COUNT = 4
+    PGW_OPT_LOOP_GUESS = 4,   /* passes the next file's first multi-pass launch runs (1..8); updated by every file to its own pass
+                                 count (consecutive ERA5 files of a run need the same number); initial value 6                  */
+    PGW_OPT_COUNT = 5
 };
 
 /* ---------------------------------------------------------------- context ------------ */
@@ -286,7 +289,8 @@ typedef struct pgw_file_args {
     void *PS_out, *T_out, *QV_out, *U_out, *V_out, *hur_pgw_out;
     void *T_SKIN_out, *T_SO_out, *FR_SEA_ICE_out;
     /* results */
-    int n_iter, _pad1;
+    int n_iter;
+    int passes_launched;  /* passes the loop kernels executed, including passes speculated beyond convergence (multi-pass launches) */
     unsigned long long levels_touched;
     double max_err_hist[32];
 } pgw_file_args;

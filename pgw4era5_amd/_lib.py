@@ -23,10 +23,10 @@ PGW_F32, PGW_F64 = 0, 1
 EXTRAP = {'off': 0, 'linear': 1, 'constant': 2, 'nan': 3}
 KERNEL_IDS = dict(pressure=0, q_to_rh=1, rh_to_q=2, integ_geopot=3, interp_logp=4, time_lerp=5,
                   vert_interp_delta=6, adjust_ps_step=7, regrid=8, surface=9, finalize=10,
-                  thermo_delta=11, wind_delta=12, phi_ref_hybrid=13, quad_delta=14, byteswap=15, harmonic=16, gauss_interp=17)
+                  thermo_delta=11, wind_delta=12, phi_ref_hybrid=13, quad_delta=14, byteswap=15, harmonic=16, gauss_interp=17, ps_loop_multi=18)
 
 # enum pgw_option (include/pgw_hip.h)
-OPTIONS = dict(quad=0, full_column=1, force_vec1=2, multipass=3)
+OPTIONS = dict(quad=0, full_column=1, force_vec1=2, multipass=3, loop_guess=4)
 
 PGW_OK = 0
 PGW_ERR_HIP = 1
@@ -107,7 +107,7 @@ class FileArgs(C.Structure):
         [(n, C.c_double) for n in ('x_hi', 'x_new', 'p_ref', 'adj_factor', 'thresh')] +
         [(n, C.c_void_p) for n in ('PS_out', 'T_out', 'QV_out', 'U_out', 'V_out', 'hur_pgw_out',
                                    'T_SKIN_out', 'T_SO_out', 'FR_SEA_ICE_out')] +
-        [('n_iter', C.c_int), ('_pad1', C.c_int), ('levels_touched', C.c_ulonglong),
+        [('n_iter', C.c_int), ('passes_launched', C.c_int), ('levels_touched', C.c_ulonglong),
          ('max_err_hist', C.c_double * 32)])
 
 

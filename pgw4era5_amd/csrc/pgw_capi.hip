@@ -20,8 +20,11 @@ struct pgw_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     long long err_col = -1;
-    DevStatus *d_status = nullptr;     // device; [1] = alternate block of the loop passes (cleared by the pass before)
-    DevStatus *h_status = nullptr;     // pinned host mirror
+    DevStatus *d_status = nullptr;     // device; [1] = alternate block of the loop passes (cleared by the pass before);
+                                       // [2 .. 2 + MULTI_MAX_PASS) = per-pass blocks of the multi-pass loop kernel
+    DevStatus *h_status = nullptr;     // pinned host mirror ([0]) + [1 .. 1 + MULTI_MAX_PASS]: read-back of the multi-pass launch,
+                                       // [2 + MULTI_MAX_PASS ...): cleared template for the per-pass blocks
+    int last_passes_launched = 0;
     // options (pgw_set_option; defaults from the environment, read ONCE in pgw_ctx_create)
     int opt[PGW_OPT_COUNT];
     // vertical grid
@@ -234,9 +237,10 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
     c->opt[PGW_OPT_FULL_COLUMN] = env_flag("PGW_FULL_COLUMN", 0);
     c->opt[PGW_OPT_FORCE_VEC1] = env_flag("PGW_FORCE_VEC1", 0);
     c->opt[PGW_OPT_MULTIPASS] = env_flag("PGW_MULTIPASS", 1);
+    c->opt[PGW_OPT_LOOP_GUESS] = 6;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&c->d_status, 2 * sizeof(DevStatus)) != hipSuccess ||
-        hipHostMalloc(&c->h_status, sizeof(DevStatus)) != hipSuccess ||
+        hipMalloc(&c->d_status, (2 + MULTI_MAX_PASS) * sizeof(DevStatus)) != hipSuccess ||
+        hipHostMalloc(&c->h_status, (2 + 2 * MULTI_MAX_PASS) * sizeof(DevStatus)) != hipSuccess ||
         hipMalloc(&c->d_small, SMALL_BYTES) != hipSuccess ||
         hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) {
         pgw_ctx_destroy(c);            // releases whatever was created before the failure
@@ -836,9 +840,13 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     int *pref_idx = (int *)(pref_f + n2);
     const int full_column = ctx->opt[PGW_OPT_FULL_COLUMN];
     const bool local = local_nplev > 0;
+    // several passes per launch: fixed p_ref, wave-level early exit (the full-column option is a per-pass traffic probe)
+    const bool multipass = !local && ctx->opt[PGW_OPT_MULTIPASS] && !full_column;
     PlevTable ptf;
     memset(&ptf, 0, sizeof(ptf));
-    if (local) {
+    if (multipass) {
+        // phi_ref of the ERA state, g * dzg and the zeroed state are produced by the first k_ps_loop_multi launch
+    } else if (local) {
         ptf.n = local_nplev;
         for (int i = 0; i < local_nplev; ++i) ptf.p[i] = plev_file[i];
         HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
@@ -858,6 +866,97 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                                delta_ps, adj_ps);                                       // + delta_ps = adj_ps = 0  :182-184
             (void)V;
         });
+    }
+
+    if (multipass) {
+        // ---- several passes per launch (k_ps_loop_multi); the reference's control flow is applied to the recorded maxima
+        void *histv = nullptr;
+        if ((rc = ws_get(ctx, 6, (size_t)n2 * MULTI_MAX_PASS * sizeof(double), &histv))) return rc;
+        double *dps_hist = (double *)histv;
+        DevStatus *mst = ctx->d_status + 2;                                // device per-pass blocks
+        DevStatus *hback = ctx->h_status + 1;                              // [0] = block 0 (ERA-state scan / earlier kernels), [1..] passes
+        DevStatus *hzero = ctx->h_status + 2 + MULTI_MAX_PASS;
+        for (int k = 0; k < MULTI_MAX_PASS; ++k) {
+            memset(&hzero[k], 0, sizeof(DevStatus));
+            hzero[k].col = ~0ull; hzero[k].min_targ_bits = ~0ull; hzero[k].min_src_bits = ~0ull;
+        }
+        if (!status_armed && (rc = status_reset(ctx))) return rc;
+        int it = 1;
+        bool first = true;
+        unsigned long long touched = 0;
+        const double *conv = nullptr;
+        int launched = 0;
+        const void *era_T = T, *era_QV = QV;                               // `T` names the storage type inside the dispatch macro
+        while (!conv) {
+            const int allowed = max_n_iter - (it - 1);                     // passes it .. max_n_iter may still run (:313-319)
+            int np = first ? ctx->opt[PGW_OPT_LOOP_GUESS] : 2;
+            if (np > MULTI_MAX_PASS) np = MULTI_MAX_PASS;
+            if (np > allowed) np = allowed;
+            if (np < 1) np = 1;                                            // also guards a caller-set guess <= 0
+            HIPCHK(ctx, hipMemcpyAsync(mst, hzero, sizeof(DevStatus) * np, hipMemcpyHostToDevice, ctx->stream));
+            {
+                #ifndef MULTI_MAXV
+#define MULTI_MAXV 1       // one column per lane: 126 VGPRs, 4 waves per SIMD (two columns: 178 VGPRs, 2 waves; measured 1.36 vs 1.39 ms)
+#endif
+                int vec = pick_vec(ctx, dtype, ncol, {ta_pgw, evap, era_T, era_QV, PS, FIS, phi_era, dphi, delta_ps, adj_ps, dps_hist}, MULTI_MAXV);
+                Levels lv = levels_of(ctx);
+                Prof pr(ctx, PGW_K_PS_LOOP_MULTI);
+                DISPATCH_TLV(dtype, ref, vec, {
+                    DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
+                    hipLaunchKernelGGL((k_ps_loop_multi<T, TL, V, STEP_U, REF>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0, ctx->stream,
+                                       lv, ntime, ncol, (const T *)era_T, (const T *)era_QV, (const TL *)ta_pgw, (const TL *)evap,
+                                       (const T *)PS, (const T *)FIS, z, phi_era, dphi, delta_ps, adj_ps, dps_hist, p_ref,
+                                       adj_factor, first ? 1 : 0, np, ctx->d_status, mst);
+                });
+            }
+            HIPCHK(ctx, hipGetLastError());
+            launched += np;
+            HIPCHK(ctx, hipMemcpyAsync(hback, ctx->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(hback + 1, mst, sizeof(DevStatus) * np, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (first && hback[0].code != 0) {                             // earlier kernels of the file / the ERA-state scan
+                *ctx->h_status = hback[0];
+                ctx->err_col = (long long)hback[0].col;
+                ctx->err = status_text(hback[0].code);
+                return hback[0].code;
+            }
+            for (int k = 0; k < np && !conv; ++k) {
+                const DevStatus &h = hback[1 + k];
+                if (h.code != 0) {
+                    ctx->err_col = (long long)h.col;
+                    ctx->err = status_text(h.code);
+                    return h.code;
+                }
+                double err_k = NAN;                                        // xarray .max() of an all-NaN field
+                if (h.valid) memcpy(&err_k, &h.max_bits, 8);
+                touched += h.levels_touched;
+                if (max_err_hist && it - 1 < hist_len) max_err_hist[it - 1] = err_k;
+                it += 1;                                                   // :313
+                if (it > max_n_iter) {                                     // :315-319
+                    if (n_iter) *n_iter = it - 1;
+                    ctx->last_passes_launched = launched;
+                    ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
+                    ctx->err_col = -1;
+                    return PGW_ERR_NOT_CONVERGED;
+                }
+                if (!(err_k > thresh)) conv = dps_hist + (size_t)k * n2;   // :189  (NaN stops the loop too)
+            }
+            first = false;
+        }
+        ctx->opt[PGW_OPT_LOOP_GUESS] = (it - 1) < 1 ? 1 : ((it - 1) > MULTI_MAX_PASS ? MULTI_MAX_PASS : (it - 1));
+        ctx->last_levels_touched = touched;
+        ctx->last_passes_launched = launched;
+        if (n_iter) *n_iter = it - 1;
+        if (ps_pgw || hus_pgw) {
+            int vec = pick_vec(ctx, dtype, ncol, {PS, evap, ps_pgw, hus_pgw, conv});
+            Levels lv = levels_of(ctx);
+            Prof pr(ctx, PGW_K_FINALIZE);
+            DISPATCH_TLV(dtype, ref, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, TL, V, REF>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                                             ctx->stream, lv, ntime, ncol, (const T *)PS, conv, (const TL *)evap,
+                                                             (T *)ps_pgw, (TL *)hus_pgw, qv_done_levels));
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return PGW_OK;
     }
 
     double phi_ref_max_error = INFINITY;                                   // :186
@@ -1080,6 +1179,7 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                      a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev,
                      !check_top && !a->local_p_ref, qv_done, ref);
     a->levels_touched = ctx->last_levels_touched;
+    a->passes_launched = ctx->last_passes_launched;
     return rc;
 }
 

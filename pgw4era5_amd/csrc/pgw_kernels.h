@@ -1601,6 +1601,109 @@ __global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z,
     }
 }
 
+// -------------------------------------------------------------------------------------
+// Several passes of the loop in ONE launch (fixed p_ref).  A column's trajectory delta_ps(k) depends on that column
+// alone - only the stopping test max|err| <= thresh is global (step_03:189, 308) - so a block can run `npass` passes
+// on its columns back to back and leave, per pass, the block maxima (status block k) and the delta_ps the pass used
+// (dps_hist[k]); the host then applies the reference's control flow to the recorded maxima and finalises from the
+// first pass that met the threshold.  Passes beyond it were speculated and are discarded.
+// What this buys is NOT memory traffic (the pass is bound by fp64 issue and latency, not by HBM: the float32-storage
+// build reads half the bytes in the same time) but the fixed cost of a launch (block dispatch, table staging, tail:
+// 0.03-0.045 ms of a 0.22 ms pass) and one host round trip per pass.  Each pass re-reads its rows (L2 / Infinity Cache / HBM).
+// `first` != 0 (first launch of a file): phi_ref of the ERA state (step_03:280-287) and g * dzg (:292-295) are computed
+// here and stored for continuation launches; delta_ps = adj_ps = 0 (:182-184).
+// -------------------------------------------------------------------------------------
+constexpr int MULTI_MAX_PASS = 8;
+template <typename T, typename TL, int V, int U, bool REF>
+__global__ __launch_bounds__(BLOCK, 3) void k_ps_loop_multi(Levels lv, int ntime, long long ncol,
+                                                         const T *__restrict__ Tera, const T *__restrict__ QVera,
+                                                         const TL *__restrict__ ta, const TL *__restrict__ evap,
+                                                         const T *__restrict__ PS, const T *__restrict__ FIS,
+                                                         DeltaSrc<T> zg, double *__restrict__ phi_ref_era,
+                                                         double *__restrict__ dphi_clim,
+                                                         double *__restrict__ delta_ps, double *__restrict__ adj_ps,
+                                                         double *__restrict__ dps_hist /* [npass][ntime*ncol] */,
+                                                         double p_ref_s, double adj_factor, int first, int npass,
+                                                         DevStatus *st0 /* errors of the ERA-state scan */,
+                                                         DevStatus *st /* [npass] */) {
+    __shared__ unsigned long long s_max[MULTI_MAX_PASS];          // per pass: max |err| as ordered bits, #valid, levels read
+    __shared__ unsigned int s_valid[MULTI_MAX_PASS];
+    __shared__ unsigned long long s_touched[MULTI_MAX_PASS];
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    if (threadIdx.x < MULTI_MAX_PASS) { s_max[threadIdx.x] = 0ull; s_valid[threadIdx.x] = 0u; s_touched[threadIdx.x] = 0ull; }
+    LevTab lt = stage_levels<true, true>(lv, s_lev, BLOCK);        // ends with a barrier
+    const long long n2 = (long long)ntime * ncol;
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    long long ngroups = n2 / V;
+    if (g < ngroups) {
+        ColIdx ix = col_index(g, V, ncol);
+        const int N = lv.nlev;
+        long long c2 = ix.t * ncol + ix.c;
+        const long long lbase = ix.t * N * ncol + ix.c;
+        double ps0[V], z[V], dps[V], adj[V], pref[V], tlow[V], phi_ref[V], phi_era[V], dphi[V];
+        loadv<T, V>(PS + c2, ps0);
+        loadv<T, V>(FIS + c2, z);
+#pragma unroll
+        for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
+        if (first) {
+            int touched0 = 0;
+            scan_columns<T, V, U, true, REF>(lv, lt, ncol, Tera + lbase, QVera + lbase, ps0, z, pref, 0, st0, c2, phi_era, tlow, touched0);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                if (REF && !zg.a) dphi[v] = (double)((float)zg.b[c2 + v] * (float)CON_G);      // see k_dphi_clim
+                else dphi[v] = zg.template get<REF>(c2 + v) * CON_G;                             // step_03:292-295
+                dps[v] = 0.0; adj[v] = 0.0;                                                      // :182-184
+            }
+            storev<double, V>(phi_ref_era + c2, phi_era);
+            storev<double, V>(dphi_clim + c2, dphi);
+        } else {
+            loadv<double, V>(phi_ref_era + c2, phi_era);
+            loadv<double, V>(dphi_clim + c2, dphi);
+            loadv<double, V>(delta_ps + c2, dps);
+            loadv<double, V>(adj_ps + c2, adj);
+        }
+        for (int k = 0; k < npass; ++k) {
+            double ps[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                dps[v] = next_delta_ps<REF>(dps[v], adj[v]);              // step_03:192
+                ps[v] = ps_of<REF>(ps0[v], dps[v]);                       // :193
+            }
+            storev<double, V>(dps_hist + (long long)k * n2 + c2, dps);
+            int touched = 0;
+            scan_columns<TL, V, U, false, REF>(lv, lt, ncol, ta + lbase, evap + lbase, ps, z, pref, 0, st + k, c2, phi_ref, tlow,
+                                               touched);
+            double amax = -1.0;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                double err = (phi_ref[v] - phi_era[v]) - dphi[v];                         // :289,298
+                const double fps = REF ? (double)((float)(-adj_factor) * (float)ps[v]) : -adj_factor * ps[v];
+                adj[v] = fps / (CON_RD * tlow[v]) * err;                                  // :301-304
+                double ae = fabs(err);
+                if (ae == ae) amax = fmax(amax, ae);                                      // :308 skipna
+            }
+            double wm = wave_max(amax);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) touched += __shfl_xor(touched, off, 64);
+            if ((threadIdx.x & 63) == 0) {
+                if (wm >= 0.0) { atomicMax(&s_max[k], dbits(wm)); atomicAdd(&s_valid[k], 1u); }
+                atomicAdd(&s_touched[k], (unsigned long long)touched);
+            }
+        }
+        storev<double, V>(delta_ps + c2, dps);            // state after the last pass: a continuation launch resumes here
+        storev<double, V>(adj_ps + c2, adj);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < npass) {
+        const int k = threadIdx.x;
+        if (s_valid[k]) {
+            atomicMax(&st[k].max_bits, s_max[k]);
+            atomicAdd(&st[k].valid, 1ull);
+        }
+        atomicAdd(&st[k].levels_touched, s_touched[k]);
+    }
+}
+
 // surface riders with the time lerp of the three 2-D deltas fused in (step_03:103-146)
 // REF: the sea-ice fraction the blend sees is the float32 value stored back into the file's array (step_03:105-107), and
 // `ice + land`, `1 - frac` are float32 operations on the file's float32 fractions (functions.py:1183-1184)

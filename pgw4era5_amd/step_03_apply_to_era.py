@@ -226,7 +226,7 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
         a.hur_pgw_out = buf('_hur_pgw', T.shape, dt4).ptr
     ctx._check(lib.pgw_step03_file(h, C.byref(a)))
     info = dict(n_iter=a.n_iter, max_err=[a.max_err_hist[i] for i in range(min(a.n_iter, 32))],
-                levels_touched=int(a.levels_touched))
+                levels_touched=int(a.levels_touched), passes_launched=int(a.passes_launched))
     return out, info
 
 

@@ -173,8 +173,9 @@ def test_step02_cli_regridding(tmp_path):
     assert res['tas'].dims == ('time', 'lat', 'lon') and res['tas'].dtype == np.float32
     want = O.regrid_lat_lon(g['field'][:, 0].astype(np.float32), g['src_lat'], g['src_lon'], g['targ_lat'], g['targ_lon'])
     np.testing.assert_allclose(res['tas'].values, want, rtol=1e-6, atol=1e-6)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError) as e:                       # no tos files in the input directory (step_02:137-140)
         s2.main(['regridding', '-i', str(inp), '-o', str(out), '-e', str(tmp_path / 'era.nc'), '-v', 'tos'])
+    assert 'Files for variable tos are missing' in str(e.value)
 
 
 def test_step03_cli_two_worker_ranks(files):

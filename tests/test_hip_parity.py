@@ -890,7 +890,8 @@ def test_whole_file_errors_reach_python():
 
 
 @pytest.mark.parametrize('opts', [dict(quad=0), dict(full_column=1), dict(force_vec1=1), dict(multipass=0),
-                                  dict(multipass=0, full_column=1), dict(quad=0, multipass=0, force_vec1=1)])
+                                  dict(multipass=0, full_column=1), dict(quad=0, multipass=0, force_vec1=1),
+                                  dict(loop_guess=1), dict(loop_guess=2), dict(loop_guess=5), dict(loop_guess=8)])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_kernel_variants_are_bit_identical(opts, dtype):
     """Every selectable variant of the file path (pgw_set_option: pair kernels instead of the quad kernel, full-column
@@ -904,9 +905,15 @@ def test_kernel_variants_are_bit_identical(opts, dtype):
     old = {k: ctx.set_option(k, v) for k, v in opts.items()}
     try:
         b = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, ref_dtype=False)
+        if 'loop_guess' in opts:
+            # a first launch of 1, 2, 5 or 8 passes (the file needs 6): continuation launches / speculated passes;
+            # afterwards the guess is the file's own pass count
+            assert ctx.get_option('loop_guess') == b['n_iter']
+            assert b['passes_launched'] >= b['n_iter'] and (opts['loop_guess'] != 8 or b['passes_launched'] == 8)
     finally:
         for k, v in old.items():
-            ctx.set_option(k, v)
+            if k != 'loop_guess':
+                ctx.set_option(k, v)
     assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
     for k in ['PS', 'T', 'QV', 'U', 'V', 'RELHUM_pgw']:
         if k == 'QV' and dtype == np.float32:
