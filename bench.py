@@ -476,6 +476,22 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
                                  note='pinned H2D of T,QV,U,V + path + D2H of T,QV,U,V on one stream')
     for v in res.values():
         v.free()
+    # step_02 for tos / siconc: 12 months of an ocean-grid delta (802 x 404 curvilinear points, NaN over land) onto the ERA5 grid
+    try:
+        oc = synthetic.make_ocean_grid_case(nj=404, ni=802, ntime=12, seed=6, land_patches=6)
+        lat = np.linspace(-90.0, 90.0, a.nlat); lon = np.arange(a.nlon) * (360.0 / a.nlon)
+        ctx.profile(True); ctx.profile_reset()
+        t0 = time.perf_counter()
+        r = F.gauss_interp_fields(np.zeros((a.nlat, a.nlon)), lat, lon, oc['latitude'], oc['longitude'], list(oc['values']), 1.0e6, 4.0)
+        wall = time.perf_counter() - t0
+        cnt, ms = ctx.profile_get('gauss_interp')
+        ctx.profile(False); ctx.profile_reset()
+        out['gauss_interp_tos_12_months'] = dict(kernel_ms=round(ms / max(cnt, 1), 3), wall_s_incl_host_geometry=round(wall, 2),
+                                                 source_points=int((~np.isnan(oc['values'][0])).sum()) * 3, targets=a.nlat * a.nlon,
+                                                 valid_targets=int((~np.isnan(r[0])).sum()))
+        del r, oc
+    except Exception as e:      # noqa: BLE001
+        out['gauss_interp_tos_12_months'] = {'error': '%s: %s' % (type(e).__name__, e)}
     # float32 storage (what real ERA5 files hold), HBM-resident like `value`: both modes of settings.f32_file_mode
     if dt == np.float64:
         try:

@@ -102,6 +102,15 @@ def main():
             for c in ('SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU'):
                 if c in m:
                     d[c] = m[c]
+            if m.get('GRBM_GUI_ACTIVE') and 'SQ_WAVE_CYCLES' in m:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs: /8 = the launch's duration in shader-clock cycles; 1024 SIMDs
+                simd_cycles = m['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0
+                d['shader_cycles'] = m['GRBM_GUI_ACTIVE'] / 8.0
+                d['mean_waves_per_simd'] = 4.0 * m['SQ_WAVE_CYCLES'] / simd_cycles
+                if 'SQ_ACTIVE_INST_VALU' in m:
+                    d['simd_valu_busy'] = 4.0 * m['SQ_ACTIVE_INST_VALU'] / simd_cycles
+                    if m.get('SQ_INSTS_VALU'):
+                        d['cycles_per_valu_inst'] = 4.0 * m['SQ_ACTIVE_INST_VALU'] / m['SQ_INSTS_VALU']
             if 'SQ_WAVE_CYCLES' in m and m['SQ_WAVE_CYCLES'] > 0:
                 for c, name in (('SQ_ACTIVE_INST_VALU', 'valu_active_share_of_wave_time'),
                                 ('SQ_WAIT_INST_ANY', 'issue_stall_share_of_wave_time'),

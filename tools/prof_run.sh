@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes of bench.py for profiles/: kernel trace (+stats) and three PMC passes (separate, as MI355X_MICROARCH.md asks).
-# usage: bash tools/prof_run.sh <tag> [storage args...]     -> gpurun_out/prof_<tag>/{trace,fetch,write,sq}
+# usage: bash tools/prof_run.sh <tag> [bench args...]     -> gpurun_out/prof_<tag>/{trace,fetch,write,sq}; summaries into profiles/
 tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
@@ -10,12 +10,11 @@ P="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-streams 0 -
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $B > $out/bench_trace.json 2> $out/trace.err || echo "trace failed"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- $P > $out/bench_fetch.json 2> $out/fetch.err || echo "fetch failed"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- $P > $out/bench_write.json 2> $out/write.err || echo "write failed"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sq -- $P > $out/bench_sq.json 2> $out/sq.err || echo "sq failed"
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $out/sq2 -- $P > $out/bench_sq2.json 2> $out/sq2.err || echo "sq2 failed"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/sq -- $P > $out/bench_sq.json 2> $out/sq.err || echo "sq failed"
 python3 profiles/summarize.py trace ${tag} $out/trace 2 10 > $out/summ_trace.log 2>&1
 python3 profiles/summarize.py ${tag} $out/trace $out/fetch $out/write $out/sq > $out/summ_pmc.log 2>&1
+python3 profiles/summarize.py trace ${tag} $out/trace 2 10 > $out/summ_trace.log 2>&1
 cp profiles/kernel_stats_${tag}.csv profiles/pmc_summary_${tag}.json $out/ 2>/dev/null
 # keep the merged-back directory small: per-dispatch counter tables are large
 find $out -name "*counter_collection.csv" -size +3M -delete
 find $out -name "*kernel_trace.csv" -size +3M -delete
-ls -la $out
