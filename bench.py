@@ -611,6 +611,19 @@ def _profile_tag(a):
     return a.storage if a.storage == 'f64' else ('f32' if a.f32_mode == 'fast' else 'f32ref')
 
 
+def _instantiation_ok(name, a):
+    """The PMC passes also see the float32 instantiations of the `f32_storage` side measurement: keep the kernels of
+    this run's storage types - <T, TL, ...> = <double, double> / <float, double> (reference mode) / <float, float>."""
+    if '<' not in name:
+        return True
+    args = [x.strip() for x in name[name.index('<') + 1:].split(',')]
+    t = args[0]
+    tl = args[1] if len(args) > 1 and args[1] in ('double', 'float') else None
+    want_t = 'double' if a.storage == 'f64' else 'float'
+    want_tl = 'double' if (a.storage == 'f64' or a.f32_mode == 'reference') else 'float'
+    return t == want_t and (tl is None or tl == want_tl)
+
+
 def rocprof_frac(kernel, a, algo_GB):
     """The roofline fraction recomputed from the committed rocprofv3 --kernel-trace summary of this same command
     (profiles/kernel_stats_<tag>_<storage>.csv, written by profiles/summarize.py from the per-dispatch trace with the
@@ -624,7 +637,7 @@ def rocprof_frac(kernel, a, algo_GB):
         return {}
     pat = PMC_KERNEL.get(kernel, '?')
     for r in csv.DictReader(open(files[-1])):
-        if r['kernel'].startswith(pat) and 'timed_avg_us' in r and r['timed_avg_us']:
+        if r['kernel'].startswith(pat) and _instantiation_ok(r['kernel'], a) and 'timed_avg_us' in r and r['timed_avg_us']:
             avg = float(r['timed_avg_us'])
             return {'frac_rocprof': round(algo_GB / (avg / 1e6) / HBM_PEAK_GBS, 4), 'rocprof_timed_avg_launch_ms': round(avg / 1e3, 4),
                     'rocprof_timed_launches': int(r['timed_calls']), 'rocprof_source': os.path.relpath(files[-1], ROOT)}
@@ -650,7 +663,7 @@ def pmc_traffic(kernel, a):
         match = lambda k: k.startswith('k_delta_pair<') and k[len('k_delta_pair<'):].split(', ')[2] == want
     else:
         match = lambda k: k.startswith(pat)
-    vals = [v['hbm_bytes_per_launch'] for k, v in d.items() if match(k) and 'hbm_bytes_per_launch' in v]
+    vals = [v['hbm_bytes_per_launch'] for k, v in d.items() if match(k) and _instantiation_ok(k, a) and 'hbm_bytes_per_launch' in v]
     if not vals:
         return None, None
     return round(sum(vals) / len(vals) / 1e9, 4), os.path.relpath(files[-1], ROOT)
@@ -675,12 +688,14 @@ def pmc_valu(kernel, a, avg_ms):
     for k, v in d.items():
         ok = (k.startswith('k_delta_pair<') and k[len('k_delta_pair<'):].split(', ')[2] == want) if 'k_delta_pair' in pat \
             else k.startswith(pat)
-        if ok and 'SQ_INSTS_VALU' in v:
+        if ok and _instantiation_ok(k, a) and 'SQ_INSTS_VALU' in v:
             rate = v['SQ_INSTS_VALU'] * 64 / (avg_ms / 1e3)
             return {'valu_wave_insts_per_launch': round(v['SQ_INSTS_VALU']), 'lane_ops_per_s': round(rate / 1e12, 2),
                     'unit': 'T lane-ops/s', 'peak': FP64_VALU_PEAK_LANE_OPS / 1e12,
                     'frac_of_fp64_issue_peak': round(rate / FP64_VALU_PEAK_LANE_OPS, 3),
                     'valu_active_share_of_wave_time': round(v.get('valu_active_share_of_wave_time', 0), 3),
+                    'simd_valu_busy': round(v['simd_valu_busy'], 3) if 'simd_valu_busy' in v else None,
+                    'mean_waves_per_simd': round(v['mean_waves_per_simd'], 2) if 'mean_waves_per_simd' in v else None,
                     'source': os.path.relpath(files[-1], ROOT)}
     return None
 
