@@ -1317,13 +1317,20 @@ extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, in
             if (south_row >= 0 || north_row >= 0)
                 hipLaunchKernelGGL((k_zonal_mean_rows<T>), dim3(nblocks(nfield * 2 * 64, BLOCK)), dim3(BLOCK), 0, ctx->stream, nfield,
                                    nlat_s, nlon_s, (const T *)src, south_row, north_row, dpole);
-            // z-slices: enough blocks to fill 256 CUs several times over even for small target grids
-            long long xy = (long long)nblocks(nlon_t, BLOCK) * nlat_t;
+            // two target longitudes per thread (one 16-B / 8-B store per plane) when the row length and the output
+            // alignment allow; z-slices: enough blocks to fill 256 CUs several times over even for small target grids
+            const int W = (nlon_t % 2 == 0 && ((uintptr_t)out % (2 * sizeof(T))) == 0 && !ctx->opt[PGW_OPT_FORCE_VEC1]) ? 2 : 1;
+            const unsigned int bx = nblocks(nlon_t, BLOCK * W);
+            long long xy = (long long)bx * nlat_t;
             long long want = (8192 + xy - 1) / xy;
             unsigned int gz = (unsigned int)(want < 1 ? 1 : (want > nfield ? nfield : want));
             // 4 planes per step (2: 6 % slower, 8: the same); ~8 k blocks (40 k: 14 % slower, one z-slice: 3 % slower)
-            hipLaunchKernelGGL((k_regrid<T, 4>), dim3(nblocks(nlon_t, BLOCK), nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                               nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+            if (W == 2)
+                hipLaunchKernelGGL((k_regrid<T, 4, 2>), dim3(bx, nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+            else
+                hipLaunchKernelGGL((k_regrid<T, 4, 1>), dim3(bx, nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
         });
     }
     HIPCHK(ctx, hipGetLastError());

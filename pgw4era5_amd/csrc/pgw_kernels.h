@@ -1312,68 +1312,90 @@ struct RegridTables {
     const double *lon_dx, *lon_Dx;
 };
 
-// A block owns 256 consecutive target longitudes of one target latitude row and walks the fields (time x plev
-// planes).  All its points interpolate between the same two source rows, and 256 target longitudes of a 0.25 deg
-// grid fall on ~70 consecutive source columns, so per plane the block first does the LATITUDE pass once per needed
-// source column (coalesced loads of the two source rows; the values the reference's first interp1d produces at
-// those columns, :859) into LDS, and each thread then takes its two neighbours from LDS for the LONGITUDE pass
-// (:892) - instead of four uncoalesced 8-byte gathers per output, which kept the texture-address path, not HBM,
-// busy (2.4 TB/s).  Arithmetic per output value is unchanged: slope*(x_new-x_lo)+y_lo as scipy interp1d, twice.
+// A block owns 256 * W consecutive target longitudes of one target latitude row (W = 2 where the row length allows:
+// each thread then stores two adjacent values per plane as one 16-B store - the kernel is write-dominated, 1.89 of its
+// 2.03 GB, and 8-B-per-lane stores reached 3.4 TB/s where the 16-B kernels of this library reach 5.5-6) and walks the
+// fields (time x plev planes).  All its points interpolate between the same two source rows, and 512 target longitudes
+// of a 0.25 deg grid fall on ~140 consecutive source columns, so per plane the block first does the LATITUDE pass once
+// per needed source column (coalesced loads of the two source rows; the values the reference's first interp1d produces
+// at those columns, :859) into LDS, and each thread then takes its neighbours from LDS for the LONGITUDE pass (:892) -
+// instead of four uncoalesced 8-byte gathers per output, which kept the texture-address path, not HBM, busy
+// (2.4 TB/s).  Arithmetic per output value is unchanged: slope*(x_new-x_lo)+y_lo as scipy interp1d, twice.
 // Source columns are addressed relative to the first valid lane's lower neighbour, modulo nlon_s (periodic
 // wrap); a block whose points span more than REGRID_SPAN source columns (coarse or unsorted targets) gathers
 // directly like the first version.  FU planes per step; the next step's source loads are issued before this
 // step's stores.
 constexpr int REGRID_SPAN = BLOCK;       // one source column per thread
 
-template <typename T, int FU>
+template <typename T, int FU, int W>
 __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, int nlon_s, int nlat_t, int nlon_t,
                                                   const T *__restrict__ src, RegridTables tb,
                                                   const double *__restrict__ pole, T *__restrict__ out) {
     __shared__ double s_y[FU][REGRID_SPAN];
     __shared__ int s_first, s_span;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;       // target lon
-    const int j = blockIdx.y;                             // target lat
-    const bool active = i < nlon_t;
-    const int ii = active ? i : nlon_t - 1;
+    const int i0 = (blockIdx.x * BLOCK + threadIdx.x) * W;      // first target lon of this thread (W | nlon_t when W > 1)
+    const int j = blockIdx.y;                                   // target lat
+    const bool active = i0 < nlon_t;
     const int jl = tb.lat_lo[j], jh = tb.lat_hi[j];
     const double ldx = tb.lat_dx[j], lDx = tb.lat_Dx[j];
-    const int il = tb.lon_lo[ii], ih = tb.lon_hi[ii];
-    const double odx = tb.lon_dx[ii], oDx = tb.lon_Dx[ii];
     const bool lat_oob = tb.lat_oob[j] != 0;
-    const bool oob = lat_oob || tb.lon_oob[ii];
-    const bool valid = active && !tb.lon_oob[ii];
+    int il[W], ih[W];
+    double odx[W], oDx[W];
+    bool oob[W], valid[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        const int ii = active ? i0 + w : nlon_t - 1;
+        il[w] = tb.lon_lo[ii]; ih[w] = tb.lon_hi[ii];
+        odx[w] = tb.lon_dx[ii]; oDx[w] = tb.lon_Dx[ii];
+        oob[w] = lat_oob || tb.lon_oob[ii];
+        valid[w] = active && !tb.lon_oob[ii];
+    }
     const long long plane_s = (long long)nlat_s * nlon_s, plane_t = (long long)nlat_t * nlon_t;
     const bool lo_pole = jl < 0 || jl >= nlat_s, hi_pole = jh < 0 || jh >= nlat_s;
     const long long row_lo = (long long)(lo_pole ? 0 : jl) * nlon_s, row_hi = (long long)(hi_pole ? 0 : jh) * nlon_s;
     const int lo_which = jl < 0 ? 0 : 1, hi_which = jh < 0 ? 0 : 1;
-    // the two grid spacings divide every plane's differences: reciprocals once per thread (SharedDivisor)
-    const SharedDivisor by_lDx(lDx), by_oDx(oDx);
-    // source-column window of this block
-    if (threadIdx.x == 0) { s_first = BLOCK; s_span = 0; }
+    // the grid spacings divide every plane's differences: reciprocals once per thread (SharedDivisor)
+    const SharedDivisor by_lDx(lDx);
+    struct DivW { SharedDivisor d[W]; };
+    const DivW by_o = [&]() { if constexpr (W == 1) return DivW{{SharedDivisor(oDx[0])}}; else return DivW{{SharedDivisor(oDx[0]), SharedDivisor(oDx[1])}}; }();
+    const SharedDivisor (&by_oDx)[W] = by_o.d;
+    // source-column window of this block: starts at the lower neighbour of the first valid target
+    if (threadIdx.x == 0) { s_first = BLOCK * W; s_span = 0; }
     __syncthreads();
-    if (valid) atomicMin(&s_first, (int)threadIdx.x);
+#pragma unroll
+    for (int w = 0; w < W; ++w) if (valid[w]) atomicMin(&s_first, (int)threadIdx.x * W + w);
     __syncthreads();
-    const int first = s_first;                            // BLOCK if the block has no valid point
+    const int first = s_first;                            // BLOCK * W if the block has no valid point
     int c0 = 0;
-    if (first < BLOCK) c0 = tb.lon_lo[blockIdx.x * BLOCK + first];
-    int rl = il - c0, rh = ih - c0;
-    if (rl < 0) rl += nlon_s;
-    if (rh < 0) rh += nlon_s;
-    if (valid) atomicMax(&s_span, (rl > rh ? rl : rh) + 1);
+    if (first < BLOCK * W) c0 = tb.lon_lo[blockIdx.x * BLOCK * W + first];
+    int rl[W], rh[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        rl[w] = il[w] - c0; rh[w] = ih[w] - c0;
+        if (rl[w] < 0) rl[w] += nlon_s;
+        if (rh[w] < 0) rh[w] += nlon_s;
+        if (valid[w]) atomicMax(&s_span, (rl[w] > rh[w] ? rl[w] : rh[w]) + 1);
+    }
     __syncthreads();
     const int span = s_span;
     const bool staged = !lat_oob && span <= REGRID_SPAN;
     // fields of this z-slice
     long long per = (nfield + gridDim.z - 1) / gridDim.z;
     long long f0 = (long long)blockIdx.z * per, f1 = f0 + per < nfield ? f0 + per : nfield;
-    T *po = out + (long long)j * nlon_t + ii;
+    T *po = out + (long long)j * nlon_t + (active ? i0 : 0);
+    auto store = [&](long long f, const double (&r)[W]) {
+        if (W == 1) po[f * plane_t] = (T)r[0];
+        else storev<T, W>(po + f * plane_t, r);           // W * sizeof(T) aligned: W | nlon_t and W | i0
+    };
     if (staged) {
         // this thread's source column of the window (threads >= span idle in the latitude pass)
         const bool loader = (int)threadIdx.x < span;
         int col = c0 + (int)threadIdx.x;
         if (col >= nlon_s) col -= nlon_s;
         if (!loader) col = 0;
-        const int li = valid ? rl : 0, hi = valid ? rh : 0;
+        int li[W], hi[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { li[w] = valid[w] ? rl[w] : 0; hi[w] = valid[w] ? rh[w] : 0; }
         double v_lo[FU], v_hi[FU];
         auto fetch = [&](long long f) {                    // the two source rows of FU planes at this thread's column
 #pragma unroll
@@ -1392,16 +1414,21 @@ __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, 
             }
             __syncthreads();
             if (loader && f + FU < f1) fetch(f + FU);      // next planes' loads fly during this group's stores
-            double ya[FU], yb[FU];
+            double ya[FU][W], yb[FU][W];
 #pragma unroll
-            for (int u = 0; u < FU; ++u) { ya[u] = s_y[u][li]; yb[u] = s_y[u][hi]; }
+            for (int u = 0; u < FU; ++u)
+#pragma unroll
+                for (int w = 0; w < W; ++w) { ya[u][w] = s_y[u][li[w]]; yb[u][w] = s_y[u][hi[w]]; }
             __syncthreads();                               // s_y is rewritten by the next group of planes
             if (active) {
 #pragma unroll
                 for (int u = 0; u < FU; ++u) {
                     if (f + u < f1) {
-                        double r = oob ? __builtin_nan("") : by_oDx.divide(yb[u] - ya[u]) * odx + ya[u];   // lon pass :892
-                        po[(f + u) * plane_t] = (T)r;
+                        double r[W];
+#pragma unroll
+                        for (int w = 0; w < W; ++w)
+                            r[w] = oob[w] ? __builtin_nan("") : by_oDx[w].divide(yb[u][w] - ya[u][w]) * odx[w] + ya[u][w];   // lon pass :892
+                        store(f + u, r);
                     }
                 }
             }
@@ -1410,29 +1437,34 @@ __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, 
     }
     // window wider than the tile (target coarser than the source, unsorted target longitudes) or latitude out of
     // bounds: four direct gathers per point, like the first version of this kernel
-    const long long o_ll = row_lo + il, o_lh = row_lo + ih, o_hl = row_hi + il, o_hh = row_hi + ih;
     for (long long f = f0; f < f1; f += FU) {
-        double ya[FU], yb[FU];
+        double ya[FU][W], yb[FU][W];
 #pragma unroll
         for (int u = 0; u < FU; ++u) {
             long long ff = (f + u < f1) ? f + u : f1 - 1;
             const T *sp = src + ff * plane_s;
-            double a_lo = 0, b_lo = 0, a_hi = 0, b_hi = 0;
-            if (!oob) {
-                a_lo = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[o_ll];
-                b_lo = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[o_lh];
-                a_hi = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[o_hl];
-                b_hi = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[o_hh];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                double a_lo = 0, b_lo = 0, a_hi = 0, b_hi = 0;
+                if (!oob[w]) {
+                    a_lo = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[row_lo + il[w]];
+                    b_lo = lo_pole ? pole[ff * 2 + lo_which] : (double)sp[row_lo + ih[w]];
+                    a_hi = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[row_hi + il[w]];
+                    b_hi = hi_pole ? pole[ff * 2 + hi_which] : (double)sp[row_hi + ih[w]];
+                }
+                ya[u][w] = by_lDx.divide(a_hi - a_lo) * ldx + a_lo;                      // lat pass at the lower lon  :859
+                yb[u][w] = by_lDx.divide(b_hi - b_lo) * ldx + b_lo;                      // lat pass at the upper lon
             }
-            ya[u] = by_lDx.divide(a_hi - a_lo) * ldx + a_lo;                      // lat pass at the lower lon  :859
-            yb[u] = by_lDx.divide(b_hi - b_lo) * ldx + b_lo;                      // lat pass at the upper lon
         }
         if (active) {
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 if (f + u < f1) {
-                    double r = oob ? __builtin_nan("") : by_oDx.divide(yb[u] - ya[u]) * odx + ya[u];   // lon pass  :892
-                    po[(f + u) * plane_t] = (T)r;
+                    double r[W];
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        r[w] = oob[w] ? __builtin_nan("") : by_oDx[w].divide(yb[u][w] - ya[u][w]) * odx[w] + ya[u][w];   // lon pass  :892
+                    store(f + u, r);
                 }
             }
         }
