@@ -153,7 +153,9 @@ def main(argv=None):
         return 2
     dist = None
     backend = None
-    if world > 1:
+    # PGW_BENCH_FORCE_DIST=1: initialise the process group even for one rank, so that the RCCL code path (init, barrier,
+    # all-reduce on device memory, torch's HIP runtime beside the library's) can be exercised on a one-GPU box
+    if world > 1 or os.environ.get('PGW_BENCH_FORCE_DIST') == '1':
         # torch first: libpgw_hip.so then binds to the HIP runtime torch loaded (pgw4era5_amd/_lib.py)
         import torch
         import torch.distributed as dist
@@ -316,7 +318,7 @@ def main(argv=None):
                        'passes_launched_per_file': round(sum(i.get('passes_launched', 0) for i in infos) / len(infos), 2),
                        'loop_launches_per_file': round((prof['ps_loop_multi'][0] + prof['adjust_ps_step'][0]) / len(infos), 2),
                        'mean_levels_read_per_column_per_pass': round(lv_per_launch / ncol, 2)},
-            'collective': {'backend': ('rccl (torch nccl)' if backend == 'nccl' else backend) if world > 1 else None,
+            'collective': {'backend': ('rccl (torch nccl)' if backend == 'nccl' else backend) if dist is not None else None,
                            'ranks_counted_by_all_reduce': ranks_seen,
                            'use': 'barrier + MAX of the elapsed time; files are independent'},
             'roofline': roof,

@@ -199,6 +199,28 @@ def test_step03_cli_two_worker_ranks(files):
             np.testing.assert_array_equal(a[v].values, b[v].values, err_msg=v)
 
 
+def test_bench_rank_under_torch_distributed_run_with_rccl(tmp_path):
+    """The multi-rank code path of bench.py on hardware, as far as one GPU allows: one rank started by
+    torch.distributed.run, process group over RCCL (backend "nccl"), barrier and all-reduces on device memory, torch's HIP
+    runtime and libpgw_hip.so in one process; small grid.  (Two ranks cannot share one GPU under RCCL; the N > 1 launch
+    path is covered with gloo in tests/test_host_logic.py and rehearsed in profiles/bench_r02d_2rank_gloo_1gpu.json.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGW_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', '29531', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                        '--nlat', '45', '--nlon', '64', '--nlev', '40', '--no-cpu-baseline', '--no-extras', '--overlap-streams', '0'],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['collective']['backend'] == 'rccl (torch nccl)'
+    assert line['collective']['ranks_counted_by_all_reduce'] == 1 and line['value'] > 0
+
+
 def test_step03_24_hourly_files_two_ranks(tmp_path):
     """BASELINE.json configs[2] in rehearsal: 24 hourly ERA5 files (small grid) through `step_03 -p 2` - files dealt
     round-robin to two self-spawned worker ranks (both on GPU 0 of a 1-GPU box), every output file against the
