@@ -201,6 +201,66 @@ def make_ocean_grid_case(nj=40, ni=60, ntime=12, seed=0, land_patches=3):
     return dict(latitude=lat2, longitude=lon2, values=vals, times=times, land=land)
 
 
+def write_gcm_files(gcm_dir, nlat=24, nlon=48, plev=None, seed=0, ocean=(30, 44)):
+    """The input of step_02 `regridding` for ALL default variables (step_02_preproc_deltas.py:77-80): for every variable
+    `{var}_delta.nc` and `{var}_historical.nc` on a coarse Gaussian-like GCM grid (lats short of the poles, lon 0 ... 360 - d)
+    with 12 monthly records - ta, hur, ua, va, zg on `plev` (descending), tas, hurs, ts, ps 2-D - and tos, siconc on an
+    ocean model's curvilinear grid (2-D latitude / longitude, NaN over land).  Values are smooth in space so that the
+    regridded deltas are physically plausible inputs of step_03 (historical ps between 950 and 1030 hPa)."""
+    import os
+    from . import ncio
+    rng = np.random.default_rng(seed)
+    os.makedirs(gcm_dir, exist_ok=True)
+    plev = PLEV19 if plev is None else np.asarray(plev, dtype=np.float64)
+    S = len(plev)
+    x = (np.arange(nlat) + 0.5) / nlat
+    lat = (-90.0 + 180.0 * x) * (1 - 0.3 / nlat)
+    lon = np.arange(nlon) * (360.0 / nlon)
+    la, lo = np.deg2rad(lat)[:, None], np.deg2rad(lon)[None, :]
+    pat = 0.5 + 0.5 * np.cos(la) * np.sin(2 * lo + 0.3) * np.cos(1.5 * la)                 # (lat, lon) in [0, 1]
+    pat2 = 0.5 + 0.5 * np.sin(la * 2) * np.cos(lo - 0.7)
+    months = np.arange(12)
+    sea = np.cos(2 * np.pi * (months - 0.5) / 12.0)
+    times = np.array(['1995-%02d-15T12:00:00' % (m + 1) for m in months], dtype='datetime64[s]')
+    prof = np.clip(1.0 + 4.0 * np.exp(-((np.log(plev) - np.log(30000.0)) / 1.2) ** 2), 1.0, 5.0)
+    prof = np.where(plev < 10000.0, 1.0 - 3.0 * (1 - plev / 10000.0), prof)
+    h = np.clip(np.log(100000.0 / plev) / np.log(100000.0 / 100.0), 0, 1)
+
+    def f4(p, field2d, amp=1.0):
+        return amp * (1 + 0.2 * sea)[:, None, None, None] * p[None, :, None, None] * field2d[None, None]
+
+    def f3(field2d, amp=1.0):
+        return amp * (1 + 0.2 * sea)[:, None, None] * field2d[None]
+
+    v4 = dict(ta=f4(prof, 0.8 + 0.4 * pat), hur=f4(5.0 * np.cos(np.linspace(0, np.pi, S)), 2 * pat2 - 1),
+              ua=f4(np.ones(S), 2 * pat - 1, 2.0), va=f4(np.ones(S), 2 * pat2 - 1, 2.0),
+              zg=f4(20.0 + 100.0 * h ** 0.7, 0.9 + 0.2 * pat))
+    v3 = dict(tas=f3(0.8 + 0.4 * pat, 2.0), hurs=f3(1 - 2 * pat2, 2.0), ts=f3(0.8 + 0.4 * pat, 2.1),
+              ps=np.ones((12, 1, 1)) * (95000.0 + 8000.0 * pat)[None])
+    F = ncio.Field
+    for base in ('{}_delta.nc', '{}_historical.nc'):
+        scale = 1.0 if 'delta' in base else 1.0
+        for var, arr in v4.items():
+            ds = ncio.Dataset()
+            ds['time'] = F(times, ('time',)); ds['plev'] = F(plev, ('plev',), attrs=dict(units='Pa'))
+            ds['lat'] = F(lat, ('lat',)); ds['lon'] = F(lon, ('lon',))
+            ds[var] = F(arr * scale, ('time', 'plev', 'lat', 'lon'))
+            ncio.to_netcdf(ds, os.path.join(gcm_dir, base.format(var)))
+        for var, arr in v3.items():
+            ds = ncio.Dataset()
+            ds['time'] = F(times, ('time',)); ds['lat'] = F(lat, ('lat',)); ds['lon'] = F(lon, ('lon',))
+            ds[var] = F(arr * scale, ('time', 'lat', 'lon'))
+            ncio.to_netcdf(ds, os.path.join(gcm_dir, base.format(var)))
+        oc = make_ocean_grid_case(nj=ocean[0], ni=ocean[1], ntime=12, seed=seed + 1)
+        for var, vals in (('tos', 0.8 * oc['values']), ('siconc', -8.0 * oc['values'])):
+            ds = ncio.Dataset()
+            ds['time'] = F(oc['times'], ('time',))
+            ds['latitude'] = F(oc['latitude'], ('j', 'i')); ds['longitude'] = F(oc['longitude'], ('j', 'i'))
+            ds[var] = F(vals, ('time', 'j', 'i'))
+            ncio.to_netcdf(ds, os.path.join(gcm_dir, base.format(var)))
+    return dict(lat=lat, lon=lon, plev=plev, times=times)
+
+
 def write_case_files(case, era_dir, delta_dir, era_name=None):
     """Write a make_case() result as the NetCDF-3 files the step_03 driver reads: one ERA5 file
     (reference file schema) and the delta directory ({var}_delta.nc,

@@ -252,6 +252,56 @@ def test_step03_24_hourly_files_two_ranks(tmp_path):
         assert np.nanmax(np.abs(ds['QV'].values - want['QV']) / scale) < 6e-7
 
 
+def test_config5_rehearsal_step02_then_step03_two_ranks(tmp_path):
+    """BASELINE.json configs[4] in rehearsal (reduced size): end-to-end step_02 + step_03 through the command lines -
+    regridding of ALL default variables from a coarse GCM grid (bilinear; tos / siconc from an ocean model's curvilinear
+    grid through the NaN-ignoring interpolation) onto the ERA5 grid, then 48 hourly float32 ERA5 files through
+    `step_03 -p 2`; the metric the config names: max |dPS| against the CPU oracle (fed the regridded delta files), here for
+    every sixth file, with its own pass count."""
+    from pgw4era5_amd import synthetic, step_02_preproc_deltas as s2, step_03_apply_to_era as s3, ncio, settings as S
+    gcm, deltas, era_dir, out_dir = (str(tmp_path / d) for d in ('gcm', 'deltas', 'era', 'out'))
+    synthetic.write_gcm_files(gcm, nlat=24, nlon=48, seed=7)
+    base = synthetic.make_case(16, 24, 30, seed=200, dtype=np.float32, target_dt=dt.datetime(2006, 7, 15, 0))
+    cases = []
+    for h in range(48):
+        c = dict(base)
+        rng = np.random.default_rng(200 + h)
+        era = dict(base['era'])
+        era['PS'] = (base['era']['PS'] * (1 + 0.003 * rng.standard_normal(base['era']['PS'].shape))).astype(np.float32)
+        era['T'] = (base['era']['T'] + 0.5 * rng.standard_normal(base['era']['T'].shape).astype(np.float32)).astype(np.float32)
+        c['era'] = era
+        c['target_dt'] = dt.datetime(2006, 7, 15, 0) + dt.timedelta(hours=h)
+        synthetic.write_case_files(c, era_dir, str(tmp_path / 'unused_deltas'))
+        cases.append(c)
+    example = os.path.join(era_dir, 'cas20060715000000.nc')
+    done = s2.main(['regridding', '-i', gcm, '-o', deltas, '-e', example])           # all 11 default variables x 2 periods
+    assert len(done) == 22
+    s3._DELTASETS.clear()
+    n_iters = s3._cli(['-i', era_dir, '-o', out_dir, '-d', deltas, '-f', '2006071500', '-l', '2006071623', '-H', '1', '-p', '2', '-t'])
+    assert len(n_iters) == 48
+    # the oracle's deltas: what step_02 wrote (decoded like the reference's xr.open_dataset)
+    darr, times, plev = {}, None, None
+    for var in ('ta', 'hur', 'ua', 'va', 'zg', 'tas', 'hurs', 'ts', 'tos', 'siconc'):
+        ds = ncio.open_dataset(os.path.join(deltas, '%s_delta.nc' % var))
+        darr[var] = ds[var].values.astype(np.float32)                               # the device holds the deltas in the ERA dtype
+        times = ds['time'].values
+        if var == 'ta':
+            plev = ds['plev'].values
+        assert ds[var].shape[-2:] == (16, 24)
+    darr['ps_hist'] = ncio.open_dataset(os.path.join(deltas, 'ps_historical.nc'))['ps'].values.astype(np.float32)
+    assert np.isnan(darr['tos']).any() and not np.isnan(darr['ta']).any()
+    worst = 0.0
+    for c, n in list(zip(cases, n_iters))[::6]:
+        want = R.pgw_for_era5_arrays(c['era'], darr, times, plev, c['target_dt'], True)
+        assert n == want['n_iter'], c['target_dt']
+        ds = ncio.open_dataset(os.path.join(out_dir, 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])), decode_times=False)
+        worst = max(worst, float(np.max(np.abs(ds['PS'].values.astype(np.float64) - want['PS']) / want['PS'])))
+        np.testing.assert_allclose(ds['T'].values, want['T'], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ds['T_SKIN'].values, want['T_SKIN'], rtol=1.3e-7, equal_nan=True)
+    print('config 5 rehearsal: 48 files, 2 ranks, max relative |dPS| vs the CPU oracle: %.2e' % worst)
+    assert worst <= 2.5e-7
+
+
 def test_step03_cli_raw_io_path_is_byte_identical(files, monkeypatch):
     """The driver's default I/O path (file bytes pread into pinned buffers, uploaded big-endian, byte order
     converted on the GPU both ways) against PGW_IO_RAW=0 (byte order converted on the host): identical output
