@@ -357,6 +357,9 @@ int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, voi
 /* diagnostic: out[i] = ln(in[i]) with the device logarithm every kernel uses (pgw_device.h
  * pgw_log: fdlibm log kernel for positive normal finite x, ocml log otherwise); device fp64 arrays */
 int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out);
+/* same for the table-driven logarithm of the hybrid-level loops (pgw_device.h pgw_log_tab: 128-entry table, r = fma(z, 1/c, -1),
+ * degree-7 polynomial; generated by tools/gen_log_table.py) */
+int pgw_test_log_table(pgw_ctx *ctx, long long n, const double *in, double *out);
 
 /* diagnostic: out[i] = pgw_exp(in[i]) (pgw_device.h: the device library's exp arithmetic written with explicit FMAs, the
  * exponential of every e_sat evaluation), ref[i] = exp(in[i]) of the device library; device fp64 arrays.  Tests require

@@ -113,6 +113,7 @@ class FileArgs(C.Structure):
 
 SIGNATURES['pgw_step03_file'] = (_i, [_vp, C.POINTER(FileArgs)])
 SIGNATURES['pgw_test_log'] = (_i, [_vp, _ll, _vp, _vp])
+SIGNATURES['pgw_test_log_table'] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES['pgw_test_exp'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_test_shared_div'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_byteswap'] = (_i, [_vp, _i, _ll, _vp, _vp])

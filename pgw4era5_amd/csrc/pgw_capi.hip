@@ -1266,7 +1266,14 @@ extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const voi
 
 extern "C" int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out) {
     NEED(ctx, n >= 1 && in && out, "bad argument");
-    hipLaunchKernelGGL(k_test_log, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out);
+    hipLaunchKernelGGL(k_test_log, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out, 0);
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+extern "C" int pgw_test_log_table(pgw_ctx *ctx, long long n, const double *in, double *out) {
+    NEED(ctx, n >= 1 && in && out, "bad argument");
+    hipLaunchKernelGGL(k_test_log, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out, 1);
     HIPCHK(ctx, hipGetLastError());
     return PGW_OK;
 }

@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "pgw_log_table.h"
 
 namespace pgw {
 
@@ -122,9 +123,9 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
 #endif
 }
 // F3: Horner steps as three-address FMAs (fma3) - for kernels whose register budget is not the binding one
-template <bool F3>
+template <bool F3, bool CHECK = true>
 __device__ __forceinline__ double pgw_log_impl(double x) {
-    if (__builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0))
+    if (CHECK && __builtin_expect(!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308), 0))
         return log(no_speculate(x));
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
@@ -157,6 +158,49 @@ __device__ __forceinline__ double pgw_log_impl(double x) {
 }
 __device__ __forceinline__ double pgw_log(double x) { return pgw_log_impl<false>(x); }
 __device__ __forceinline__ double pgw_log_f3(double x) { return pgw_log_impl<true>(x); }    // same bits
+
+// ---- table-driven natural logarithm for the level loops ------------------------------------
+// The level loops of the surface-pressure iteration are bound by fp64 issue (94 % of the SIMD cycles), and the
+// fdlibm kernel above is ~40 of their ~90 instructions per level.  Tang-style table method (the construction of
+// glibc's / ARM optimized-routines' log): x = 2^k z, z in [0.6875, 1.375) cut into 128 intervals by the top mantissa
+// bits; per interval a double invc ~ 1/centre and logc = -log(invc), the pair chosen (tools/gen_log_table.py) such that
+// logc is within 2.2e-19 of the exact value; r = fma(z, invc, -1) (|r| < 0.0040, one rounding), and
+//     log x = (k ln2_hi + logc) + r + [r^2 (A0 + A1 r + ... + A5 r^5) + k ln2_lo]     (truncation r^8/8 < 1e-20)
+// with the leading sum split exactly into hi + lo.  ~25 instructions and one 16-B LDS read.  The two intervals next to
+// z = 1 with k = 0 (results near zero, where the table's absolute accuracy is not a relative one) and everything
+// outside the positive normal range go to pgw_log.  tests/...::test_device_log_accuracy: <= 1 ulp of numpy's log.
+// The table lives in LDS (stage_log_table): lanes index it with their own interval.
+__device__ const double LOG_TABLE_DEV[2 * LOG_TABLE_N] = {
+#define PGW_LOG_TABLE_BODY
+#include "pgw_log_table.h"
+#undef PGW_LOG_TABLE_BODY
+};
+__device__ __forceinline__ void stage_log_table(double *lds, int nthreads) {      // caller synchronises afterwards
+    for (int i = threadIdx.x; i < 2 * LOG_TABLE_N; i += nthreads) lds[i] = LOG_TABLE_DEV[i];
+}
+__device__ __forceinline__ double pgw_log_tab(double x, const double *tab) {
+    const unsigned int hi = (unsigned int)__double2hiint(x);
+    const unsigned int thi = hi - 0x3FE60000u;                      // (bits(x) - OFF) >> 32; OFF's low word is 0: no borrow
+    // positive normal finite x  <=>  0x00100000 <= hi < 0x7FF00000
+    if (__builtin_expect(!(hi - 0x00100000u < 0x7FE00000u), 0)) return log(no_speculate(x));
+    const int i = (int)((thi >> 13) & 127u);
+    const int k = (int)thi >> 20;
+    if (__builtin_expect(k == 0 && (i == 79 || i == 80), 0)) return pgw_log_impl<true, true>(no_speculate(x));
+    const double z = __hiloint2double((int)(hi - (thi & 0xFFF00000u)), __double2loint(x));
+    const double invc = tab[2 * i], logc = tab[2 * i + 1];
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = __builtin_fma(kd, 0x1.62e42fefa3800p-1, logc);       // k ln2_hi is exact (11 trailing zero bits)
+    const double h = w + r;
+    const double lo = __builtin_fma(kd, 0x1.ef35793c76730p-45, (w - h) + r);
+    const double r2 = r * r;
+    double p = fma3(r, 0x1.2492492492492p-3, -0x1.5555555555555p-3);       //  1/7, -1/6
+    p = fma3(r, p, 0x1.999999999999ap-3);                                   //  1/5
+    p = fma3(r, p, -0x1.0p-2);                                              // -1/4
+    p = fma3(r, p, 0x1.5555555555555p-2);                                   //  1/3
+    p = fma3(r, p, -0x1.0p-1);                                              // -1/2
+    return __builtin_fma(r2, p, lo) + h;
+}
 
 // ---- exponential --------------------------------------------------------------------------
 // The same arithmetic as the device library's exp(double) - n = rint(x log2 e), r = x - n ln2 (two FMAs),

@@ -23,14 +23,16 @@ struct Levels {
 // prefetched row and earlier store of the wave (vmcnt retires in order) - one such load per level
 // serialises the whole software pipeline.  ds_read uses lgkmcnt and leaves vmcnt traffic in flight.
 constexpr int MAX_NLEV = 256;
-struct LevTab {            // LDS image: ak[0..N] | bk[0..N] | akm[0..N-1] | bkm[0..N-1]
-    const double *ak, *bk, *akm, *bkm;
+struct LevTab {            // LDS image: ak[0..N] | bk[0..N] | akm[0..N-1] | bkm[0..N-1] | table of pgw_log_tab
+    const double *ak, *bk, *akm, *bkm, *logtab;
 };
 template <bool HALF, bool FULL>
 __device__ __forceinline__ LevTab stage_levels(const Levels &lv, double *lds, int nthreads) {
     const int N = lv.nlev;
     LevTab t;
     t.ak = lds; t.bk = lds + (MAX_NLEV + 1); t.akm = lds + 2 * (MAX_NLEV + 1); t.bkm = t.akm + MAX_NLEV;
+    t.logtab = t.bkm + MAX_NLEV;
+    stage_log_table(lds + 2 * (MAX_NLEV + 1) + 2 * MAX_NLEV, nthreads);
     double *w = lds;
     for (int i = threadIdx.x; i <= N; i += nthreads) {
         if (HALF) { w[i] = lv.ak[i]; w[(MAX_NLEV + 1) + i] = lv.bk[i]; }
@@ -39,7 +41,7 @@ __device__ __forceinline__ LevTab stage_levels(const Levels &lv, double *lds, in
     __syncthreads();
     return t;
 }
-constexpr int LEVTAB_DOUBLES = 2 * (MAX_NLEV + 1) + 2 * MAX_NLEV;
+constexpr int LEVTAB_DOUBLES = 2 * (MAX_NLEV + 1) + 2 * MAX_NLEV + 2 * LOG_TABLE_N;
 
 // flat column group -> (time, column) and base offsets
 struct ColIdx {
@@ -168,23 +170,24 @@ __device__ __forceinline__ double rd_tv_f32(double t, double q) {
     return (double)(287.05f * tv);                               // :150  CON_RD * tav.sel(...)
 }
 
-__device__ __forceinline__ void geo_init(GeoAcc &a, double zgs, double p_bottom) {
+// `logtab`: LDS table of pgw_log_tab (the hybrid-level kernels), or nullptr: fdlibm kernel (pgw_log)
+__device__ __forceinline__ void geo_init(GeoAcc &a, double zgs, double p_bottom, const double *logtab = nullptr) {
     a.phi = zgs;
     a.p_lo = fix_p(p_bottom);
-    a.lnp_lo = pgw_log(a.p_lo);
+    a.lnp_lo = logtab ? pgw_log_tab(a.p_lo, logtab) : pgw_log(a.p_lo);
     a.dmin = __builtin_inf();
     a.kstar = -1;
     a.phi_s = a.rtv_s = a.lnp_s = 0.0;
 }
 // process layer l (between half levels l and l+1); rtv = CON_RD * tv of the layer; p_top = pa_hl[l] raw
-template <bool REF = false>
-__device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double rtv, double p_top, double p_ref) {
+template <bool REF = false, bool TAB = false>
+__device__ __forceinline__ void geo_layer(GeoAcc &a, int l, double rtv, double p_top, double p_ref, const double *logtab = nullptr) {
     double d = a.p_lo - p_ref;                        // candidate k = l+1         :160-161
     if (d >= 0 && d <= a.dmin) {
         a.dmin = d; a.kstar = l + 1; a.phi_s = a.phi; a.rtv_s = rtv; a.lnp_s = a.lnp_lo;
     }
     double p_hi = fix_p(p_top);                       // :135
-    double lnp_hi = pgw_log_f3(p_hi);                   // the log of the level loops of geopot / phi_ref / pass kernels
+    double lnp_hi = TAB ? pgw_log_tab(p_hi, logtab) : pgw_log_f3(p_hi);      // the log of the level loops
     a.phi = phi_store<REF>(a.phi + rtv * (a.lnp_lo - lnp_hi));   // :149-152, dlnpa :136-138
     a.p_lo = p_hi; a.lnp_lo = lnp_hi;
 }
@@ -292,7 +295,7 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
         double akN = lt.ak[N], bkN = lt.bk[N];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            geo_init(acc[v], z[v], akN + ps[v] * bkN);          // step_03:198
+            geo_init(acc[v], z[v], akN + ps[v] * bkN, lt.logtab);   // step_03:198
             mono[v] = ps[v] >= lv.ps_mono_min;                  // false for NaN
         }
     }
@@ -334,7 +337,11 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
                         double q = e_to_q(e[u][v], am + ps[v] * bm);                   // :196, :262-266
                         rtv = CON_RD * (t[u][v] * (1 + 0.61 * q));
                     }
-                    geo_layer<REF>(acc[v], lc, rtv, a + ps[v] * b, pref[v]);
+#ifdef PGW_NO_LOG_TABLE
+                    geo_layer<REF, false>(acc[v], lc, rtv, a + ps[v] * b, pref[v], nullptr);
+#else
+                    geo_layer<REF, true>(acc[v], lc, rtv, a + ps[v] * b, pref[v], lt.logtab);
+#endif
                 }
                 touched += V;
             }
@@ -676,9 +683,13 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
     // plev / ln(plev) staged in LDS: lanes index them with their own (divergent) scan position
     __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
     __shared__ double s_lev[LEVTAB_DOUBLES];
+    // the delta kernels take every logarithm from pgw_log_tab - like k_log_table, which makes ln(plev): the exact-hit test
+    // `src_x == targ_x` (functions.py:540) compares values of ONE implementation
     LevTab lt;
     lt.akm = lt.bkm = nullptr;
+    lt.logtab = s_lev + 2 * (MAX_NLEV + 1) + 2 * MAX_NLEV;
     if (!trgP) lt = stage_levels<false, true>(lv, s_lev, BLOCK);
+    else stage_log_table(s_lev + 2 * (MAX_NLEV + 1) + 2 * MAX_NLEV, BLOCK);
     const int S = pt.n;
     if (threadIdx.x < MAX_PLEV) {
         s_p[threadIdx.x] = pt.p[threadIdx.x];
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
                 fill_below = true;
             }
             if (bad) { report(st, 15, flat); ksfc = -1; }
-            lnps = pgw_log(pshv);
+            lnps = pgw_log_tab(pshv, lt.logtab);
         }
         auto srcx = [&](int i) -> double { return (HAS_SFC && i == ksfc) ? lnps : s_lnp[i]; };
         auto srcy = [&](int i) -> double {
@@ -734,7 +745,7 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
         for (int l = 0; l < N; ++l) {
             double p = ptg ? (double)ptg[(long long)l * ncol] : (lt.akm[l] + psv * lt.bkm[l]);
             if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
-            double x = pgw_log(p);
+            double x = pgw_log_tab(p, lt.logtab);
             if (!(x >= xprev)) j = 0;
             while (j < S) {
                 double xs = srcx(j);
@@ -821,8 +832,10 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
     __shared__ double s_lnp[MAX_PLEV];
+    __shared__ double s_logt[2 * LOG_TABLE_N];
     const int S = pt.n;
     double *s_akm = lds_pair, *s_bkm = s_akm + lv.nlev;
+    stage_log_table(s_logt, TPB);
     for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
     for (int i = threadIdx.x; i < lv.nlev; i += TPB) {
         s_akm[i] = lv.akm[i];
@@ -865,7 +878,7 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
                     fill = true;
                 }
                 if (bad) { report(st, 15, c2 + v); sc[v].ksfc = -1; fill = false; }
-                sc[v].lnps = pgw_log(pshv);
+                sc[v].lnps = pgw_log_tab(pshv, s_logt);
             }
             fillv[v] = fill; sfav[v] = sfa; sfbv[v] = sfb;
             if (check_top) {                                                  // np.min(source_P), :417
@@ -928,7 +941,7 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
                     for (int v = 0; v < V; ++v) {
                         double pa = am + ps[v] * bm;                                   // step_03:87-88
                         if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
-                        double x = pgw_log(pa);                                       // functions.py:471
+                        double x = pgw_log_tab(pa, s_logt);                           // functions.py:471
                         ColScan &c = sc[v];
                         if (!(x >= c.xprev)) c.j = 0;
                         while (c.j < S) {
@@ -1028,14 +1041,14 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
     __shared__ double s_lnp[MAX_PLEV];
+    __shared__ double s_logt[2 * LOG_TABLE_N];      // table of pgw_log_tab: every logarithm of the delta kernels (see k_vert_interp_delta)
     const int S = pt.n;
     double *s_akm = lds_quad, *s_bkm = lds_quad + lv.nlev, *s_lnpa = lds_quad + 2 * lv.nlev;
+    stage_log_table(s_logt, TPB);
     for (int i = threadIdx.x; i < MAX_PLEV; i += TPB) s_lnp[i] = pt.lnp[i];
-    for (int i = threadIdx.x; i < lv.nlev; i += TPB) {
-        const double am = lv.akm[i];
-        s_akm[i] = am; s_bkm[i] = lv.bkm[i];
-        if (i < n_pure_lv) s_lnpa[i] = pgw_log_f3(am);
-    }
+    for (int i = threadIdx.x; i < lv.nlev; i += TPB) { s_akm[i] = lv.akm[i]; s_bkm[i] = lv.bkm[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_pure_lv; i += TPB) s_lnpa[i] = pgw_log_tab(s_akm[i], s_logt);
     __syncthreads();
     long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
     double min_t = __builtin_inf(), min_s = __builtin_inf();
@@ -1072,7 +1085,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
             }
             if (bad) { report(st, 15, flat); ksfc = -1; fill = false; }
         }
-        const double lnps = pgw_log(pshv);
+        const double lnps = pgw_log_tab(pshv, s_logt);
         if (check_top) {                                                      // np.min(source_P), :417
             for (int i = 0; i < S; ++i) {
                 double p = (i == ksfc) ? pshv : pt.p[i];
@@ -1181,7 +1194,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                     if (check_top) { if (pa != pa) nanflag |= 1; else min_t = fmin(min_t, pa); }
                     double x;                                                      // functions.py:471
                     if (l < n_pure_lv) x = ps_finite ? s_lnpa[l] : pa;             // pa == akm[l]; NaN for a non-finite ps
-                    else x = pgw_log_f3(pa);
+                    else x = pgw_log_tab(pa, s_logt);
                     if (!(x >= xprev)) { j1 = 0; j2 = 0; }
                     while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
                     xprev = (x == x) ? x : __builtin_inf();
@@ -1934,10 +1947,13 @@ __global__ __launch_bounds__(BLOCK) void k_byteswap(long long n16, long long n, 
     }
 }
 
-// pgw_log over an array (diagnostic entry pgw_test_log; tests compare it with numpy's log)
-__global__ void k_test_log(long long n, const double *__restrict__ in, double *__restrict__ out) {
+// pgw_log / pgw_log_tab over an array (diagnostic entry pgw_test_log; tests compare them with numpy's log)
+__global__ void k_test_log(long long n, const double *__restrict__ in, double *__restrict__ out, int table) {
+    __shared__ double s_tab[2 * LOG_TABLE_N];
+    stage_log_table(s_tab, blockDim.x);
+    __syncthreads();
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = pgw_log(in[i]);
+    if (i < n) out[i] = table ? pgw_log_tab(in[i], s_tab) : pgw_log(in[i]);
 }
 
 // pgw_exp and the device library's exp over an array (diagnostic entry pgw_test_exp): out[i] = pgw_exp(in[i]),
@@ -1957,8 +1973,11 @@ __global__ void k_test_shared_div(long long n, const double *__restrict__ num, c
 // ln() of a small table with the device log (so table entries and per-column logs come from
 // the same implementation)
 __global__ void k_log_table(int n, const double *in, double *out) {
+    __shared__ double s_tab[2 * LOG_TABLE_N];
+    stage_log_table(s_tab, blockDim.x);
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = pgw_log(in[i]);
+    if (i < n) out[i] = pgw_log_tab(in[i], s_tab);
 }
 
 }  // namespace pgw
