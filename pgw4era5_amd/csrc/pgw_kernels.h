@@ -1659,8 +1659,11 @@ __global__ __launch_bounds__(BLOCK) void k_dphi_clim(long long n, DeltaSrc<T> z,
 // here and stored for continuation launches; delta_ps = adj_ps = 0 (:182-184).
 // -------------------------------------------------------------------------------------
 constexpr int MULTI_MAX_PASS = 8;
+#ifndef MULTI_MINW
+#define MULTI_MINW 4      // 128 VGPRs (12 bytes of scratch per lane): 1.28 -> 1.21 ms against 3 waves / 136 VGPRs; 5 waves spill 132 bytes and lose
+#endif
 template <typename T, typename TL, int V, int U, bool REF>
-__global__ __launch_bounds__(BLOCK, 3) void k_ps_loop_multi(Levels lv, int ntime, long long ncol,
+__global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, int ntime, long long ncol,
                                                          const T *__restrict__ Tera, const T *__restrict__ QVera,
                                                          const TL *__restrict__ ta, const TL *__restrict__ evap,
                                                          const T *__restrict__ PS, const T *__restrict__ FIS,
