@@ -896,7 +896,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             HIPCHK(ctx, hipMemcpyAsync(mst, hzero, sizeof(DevStatus) * np, hipMemcpyHostToDevice, ctx->stream));
             {
                 #ifndef MULTI_MAXV
-#define MULTI_MAXV 1       // one column per lane: 126 VGPRs, 4 waves per SIMD (two columns: 178 VGPRs, 2 waves; measured 1.36 vs 1.39 ms)
+#define MULTI_MAXV 1       // one column per lane (two columns: 168 VGPRs + scratch; measured 1.36 vs 1.39 ms before the log table)
 #endif
                 int vec = pick_vec(ctx, dtype, ncol, {ta_pgw, evap, era_T, era_QV, PS, FIS, phi_era, dphi, delta_ps, adj_ps, dps_hist}, MULTI_MAXV);
                 Levels lv = levels_of(ctx);
