@@ -258,6 +258,12 @@ def main(argv=None):
     micro = microbench(ctx, era, coeffs, a, np) if solo else {}       # N = 1 only: keeps multi-rank runs short
     overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a, ref) if (solo and a.overlap_streams > 1) else None
     ctx.profile(False)
+    latency = None
+    if world > 1:
+        try:
+            latency = latency_mode(ctx, a, rank, world, dist, backend, dtype, ref)
+        except Exception as e:                      # noqa: BLE001 - a side measurement; every rank fails or none (same inputs)
+            latency = {'error': '%s: %s' % (type(e).__name__, e)}
     elapsed = reduce(elapsed, 'MAX')
     ranks_seen = int(round(reduce(1.0, 'SUM')))
     iters_min = int(round(reduce(float(min(i['n_iter'] for i in infos)), 'MIN')))
@@ -326,6 +332,7 @@ def main(argv=None):
             'signature_kernels': micro,
             'extras': None,
             'overlap': overlap,
+            'latency_mode': latency,
             'device': ctx.device_name(),
             'setup_s': round(t_gen, 1),
         }
@@ -342,6 +349,47 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def latency_mode(ctx, a, rank, world, dist, backend, dtype, ref, files=6, warmup=2):
+    """SURVEY.md section 8e, row 2, measured beside `value` at N > 1: ONE file split into N latitude bands, one per rank;
+    the loop's stopping test is made global by an all-reduce MAX of the per-pass maxima (pgw_set_reduce_hook; RCCL when the
+    backend is nccl).  Every rank builds the same synthetic file (seed 1) and keeps its band.  ms per file = wall time of
+    the slowest rank between two barriers / files; a strong-scaling figure (time to one file), not files/hour."""
+    import torch
+    import numpy as np
+    from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
+    from pgw4era5_amd.parallel import band_rows, band_max_hook
+    case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1, dtype=dtype)
+    j0, j1 = band_rows(a.nlat, rank, world)
+    era = s3._upload_era(ctx, s3._band_of(case['era'], j0, j1), dtype)
+    deltas = s3.DeltaSet(ctx, s3._band_of(case['deltas'], j0, j1), case['delta_times'], case['plev'], dtype)
+    coeffs = dict(ak=case['era']['ak'], bk=case['era']['bk'], soil1=case['era']['soil1'])
+    stamps = [case['target_dt'] + dt.timedelta(hours=i) for i in range(files + warmup)]
+    out, n_iter = {}, []
+    ctx.set_reduce_hook(band_max_hook())
+    try:
+        for i in range(warmup):
+            s3.process_file_device(ctx, era, coeffs, deltas, stamps[i], True, out=out, ref_dtype=ref)
+        ctx.sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(files):
+            _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[warmup + i], True, out=out, ref_dtype=ref)
+            n_iter.append(info['n_iter'])
+        ctx.sync()
+        dist.barrier()
+        el = time.perf_counter() - t0
+    finally:
+        ctx.set_reduce_hook(None)
+    t = torch.tensor([el], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    for v in out.values():
+        v.free()
+    return {'bands': world, 'rows_of_rank0': j1 - j0, 'files': files, 'ms_per_file': round(float(t.item()) / files * 1e3, 3),
+            'iterations_per_file': n_iter[0] if len(set(n_iter)) == 1 else n_iter,
+            'exchange': 'all-reduce MAX of 1 + 3 K doubles per loop launch (K passes), %s' % ('rccl' if backend == 'nccl' else backend),
+            'scaling': 'strong (one file over all ranks)'}
 
 
 def overlap_region(device, era, coeffs, deltas, stamps, a, ref=False):

@@ -47,7 +47,8 @@ enum pgw_status {
     PGW_ERR_TOP_PRESSURE = 16,       /* 'ERA5 top pressure is lower than ...'        :417-425   */
     PGW_ERR_NOT_CONVERGED = 17,      /* 'Pressure adjustment did not converge' step_03:313-319  */
     PGW_ERR_GRID_EXTENT = 18,        /* regrid: target exceeds source    functions.py:845-888   */
-    PGW_ERR_NO_P_REF = 19            /* 'No reference pressure level above ...'  step_03:245-251 */
+    PGW_ERR_NO_P_REF = 19,           /* 'No reference pressure level above ...'  step_03:245-251 */
+    PGW_ERR_REDUCE = 20              /* the caller's reduce hook (pgw_set_reduce_hook) returned non-zero               */
 };
 
 enum pgw_dtype { PGW_F32 = 0, PGW_F64 = 1 };
@@ -87,6 +88,16 @@ int pgw_ctx_create(int device, pgw_ctx **out);
 int pgw_ctx_destroy(pgw_ctx *ctx);
 int pgw_set_option(pgw_ctx *ctx, int option, int value);
 int pgw_get_option(pgw_ctx *ctx, int option, int *value);
+/* One ERA5 file split into latitude bands over several contexts / ranks: the columns of
+ * a file are independent except for the loop's stopping test, the maximum of |phi error| over ALL columns
+ * (step_03_apply_to_era.py:189, 308).  With a hook set, pgw_step03_file hands the per-pass figures of its band to
+ * `fn(vals, n, user)`, which must replace every element by its MAXIMUM over the ranks holding the file's other bands
+ * (an 8..200-byte all-reduce per loop launch: RCCL / gloo in the caller, see pgw4era5_amd/parallel.py) and return 0.
+ * Every rank then takes the same stopping decision, and an error status of one band is returned by all.  n is the same
+ * on all ranks at every call.  fn = NULL removes the hook.  Needs the multi-pass loop (PGW_OPT_MULTIPASS = 1, fixed
+ * p_ref, PGW_OPT_FULL_COLUMN = 0). */
+typedef int (*pgw_reduce_max_fn)(double *vals, int n, void *user);
+int pgw_set_reduce_hook(pgw_ctx *ctx, pgw_reduce_max_fn fn, void *user);
 const char *pgw_last_error(pgw_ctx *ctx);
 long long pgw_error_column(pgw_ctx *ctx);
 const char *pgw_version(void);

@@ -34,6 +34,7 @@ PGW_ERR_ARG = 2
 PGW_ERR_PREF_AT_TOP = 14
 PGW_ERR_PS_HIST_ABOVE_TOP = 15
 PGW_ERR_NOT_CONVERGED = 17
+PGW_ERR_REDUCE = 20
 
 _vp, _i, _ll, _d, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_double, C.c_size_t
 _dp = C.POINTER(C.c_double)
@@ -112,6 +113,8 @@ class FileArgs(C.Structure):
 
 
 SIGNATURES['pgw_step03_file'] = (_i, [_vp, C.POINTER(FileArgs)])
+REDUCE_MAX_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)      # pgw_reduce_max_fn
+SIGNATURES['pgw_set_reduce_hook'] = (_i, [_vp, REDUCE_MAX_FN, _vp])
 SIGNATURES['pgw_test_log'] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES['pgw_test_log_table'] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES['pgw_test_exp'] = (_i, [_vp, _ll, _vp, _vp, _vp])

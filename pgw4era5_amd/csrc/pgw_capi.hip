@@ -25,6 +25,8 @@ struct pgw_ctx {
     DevStatus *h_status = nullptr;     // pinned host mirror ([0]) + [1 .. 1 + MULTI_MAX_PASS]: read-back of the multi-pass launch,
                                        // [2 + MULTI_MAX_PASS ...): cleared template for the per-pass blocks
     int last_passes_launched = 0;
+    pgw_reduce_max_fn reduce_fn = nullptr;      // latitude-band sharding of one file: MAX over the ranks (pgw_set_reduce_hook)
+    void *reduce_user = nullptr;
     // options (pgw_set_option; defaults from the environment, read ONCE in pgw_ctx_create)
     int opt[PGW_OPT_COUNT];
     // vertical grid
@@ -818,6 +820,47 @@ extern "C" int pgw_phi_ref_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long 
     return status_check(ctx);
 }
 
+// ---- latitude-band sharding (pgw_set_reduce_hook).  One vector per loop launch: [status of the kernels before the
+// loop | per pass: status, any-valid flag, max |err| (-inf when the band has no valid column)].
+static int first_launch_passes(pgw_ctx *ctx, int max_n_iter) {
+    int np = ctx->opt[PGW_OPT_LOOP_GUESS];
+    if (np > MULTI_MAX_PASS) np = MULTI_MAX_PASS;
+    if (np > max_n_iter) np = max_n_iter;
+    return np < 1 ? 1 : np;
+}
+
+static int call_reduce(pgw_ctx *ctx, double *v, int n) {
+    if (ctx->reduce_fn(v, n, ctx->reduce_user) != 0) {
+        ctx->err = "the reduce hook (pgw_set_reduce_hook) failed";
+        ctx->err_col = -1;
+        return PGW_ERR_REDUCE;
+    }
+    return PGW_OK;
+}
+
+// An error found before the loop's first launch: the other bands are about to wait in their first reduce - meet them
+// there with the status, so every rank returns it.
+static int band_fail(pgw_ctx *ctx, int code, int max_n_iter) {
+    if (!ctx->reduce_fn || code == PGW_OK) return code;
+    const std::string text = ctx->err;
+    const long long col = ctx->err_col;
+    const int np = first_launch_passes(ctx, max_n_iter);
+    double v[1 + 3 * MULTI_MAX_PASS];
+    v[0] = (double)code;
+    for (int k = 0; k < np; ++k) { v[1 + 3 * k] = 0.0; v[2 + 3 * k] = 0.0; v[3 + 3 * k] = -INFINITY; }
+    call_reduce(ctx, v, 1 + 3 * np);
+    ctx->err = text;
+    ctx->err_col = col;
+    return code;
+}
+
+extern "C" int pgw_set_reduce_hook(pgw_ctx *ctx, pgw_reduce_max_fn fn, void *user) {
+    if (!ctx) return PGW_ERR_ARG;
+    ctx->reduce_fn = fn;
+    ctx->reduce_user = fn ? user : nullptr;
+    return PGW_OK;
+}
+
 // The loop of step_03_apply_to_era.py:182-319 given the iterate-independent vapour pressure
 // `evap` = hur_pgw/100 * e_sat(ta_pgw) (functions.py:123).  Shared by pgw_adjust_ps_loop and
 // pgw_step03_file.  The host reads max|err| after every pass (status copy + stream synchronisation) before it
@@ -842,6 +885,8 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     const bool local = local_nplev > 0;
     // several passes per launch: fixed p_ref, wave-level early exit (the full-column option is a per-pass traffic probe)
     const bool multipass = !local && ctx->opt[PGW_OPT_MULTIPASS] && !full_column;
+    NEED(ctx, !ctx->reduce_fn || multipass, "a reduce hook (latitude-band sharding) needs the multi-pass loop: fixed p_ref, "
+                                            "PGW_OPT_MULTIPASS = 1, PGW_OPT_FULL_COLUMN = 0");
     PlevTable ptf;
     memset(&ptf, 0, sizeof(ptf));
     if (multipass) {
@@ -889,10 +934,9 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
         const void *era_T = T, *era_QV = QV;                               // `T` names the storage type inside the dispatch macro
         while (!conv) {
             const int allowed = max_n_iter - (it - 1);                     // passes it .. max_n_iter may still run (:313-319)
-            int np = first ? ctx->opt[PGW_OPT_LOOP_GUESS] : 2;
-            if (np > MULTI_MAX_PASS) np = MULTI_MAX_PASS;
+            int np = first ? first_launch_passes(ctx, max_n_iter) : 2;    // (a caller-set guess <= 0 counts as 1)
             if (np > allowed) np = allowed;
-            if (np < 1) np = 1;                                            // also guards a caller-set guess <= 0
+            if (np < 1) np = 1;
             HIPCHK(ctx, hipMemcpyAsync(mst, hzero, sizeof(DevStatus) * np, hipMemcpyHostToDevice, ctx->stream));
             {
                 #ifndef MULTI_MAXV
@@ -914,21 +958,33 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             HIPCHK(ctx, hipMemcpyAsync(hback, ctx->d_status, sizeof(DevStatus), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipMemcpyAsync(hback + 1, mst, sizeof(DevStatus) * np, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            if (first && hback[0].code != 0) {                             // earlier kernels of the file / the ERA-state scan
-                *ctx->h_status = hback[0];
-                ctx->err_col = (long long)hback[0].col;
-                ctx->err = status_text(hback[0].code);
-                return hback[0].code;
+            // figures of this launch; with a reduce hook: their maxima over the bands of the file
+            double red[1 + 3 * MULTI_MAX_PASS];
+            red[0] = first ? (double)hback[0].code : 0.0;
+            for (int k = 0; k < np; ++k) {
+                const DevStatus &h = hback[1 + k];
+                double e = -INFINITY;
+                if (h.valid) memcpy(&e, &h.max_bits, 8);
+                red[1 + 3 * k] = (double)h.code; red[2 + 3 * k] = h.valid ? 1.0 : 0.0; red[3 + 3 * k] = e;
+            }
+            if (ctx->reduce_fn && (rc = call_reduce(ctx, red, 1 + 3 * np))) return rc;
+            if (first && red[0] != 0.0) {                                  // earlier kernels of the file / the ERA-state scan
+                const bool mine = hback[0].code != 0;                      // (else: another band's status)
+                if (mine) *ctx->h_status = hback[0];
+                const int code = mine ? (int)hback[0].code : (int)red[0];
+                ctx->err_col = mine ? (long long)hback[0].col : -1;
+                ctx->err = status_text(code);
+                return code;
             }
             for (int k = 0; k < np && !conv; ++k) {
                 const DevStatus &h = hback[1 + k];
-                if (h.code != 0) {
-                    ctx->err_col = (long long)h.col;
-                    ctx->err = status_text(h.code);
-                    return h.code;
+                if (red[1 + 3 * k] != 0.0) {
+                    const int code = h.code != 0 ? (int)h.code : (int)red[1 + 3 * k];
+                    ctx->err_col = h.code != 0 ? (long long)h.col : -1;
+                    ctx->err = status_text(code);
+                    return code;
                 }
-                double err_k = NAN;                                        // xarray .max() of an all-NaN field
-                if (h.valid) memcpy(&err_k, &h.max_bits, 8);
+                const double err_k = red[2 + 3 * k] != 0.0 ? red[3 + 3 * k] : NAN;   // NaN: xarray .max() of an all-NaN field
                 touched += h.levels_touched;
                 if (max_err_hist && it - 1 < hist_len) max_err_hist[it - 1] = err_k;
                 it += 1;                                                   // :313
@@ -1044,6 +1100,9 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
          a->pshist_b, "delta record pointer is NULL");
     NEED(ctx, a->PS_out && a->T_out && a->QV_out && a->U_out && a->V_out, "output pointer is NULL");
     NEED(ctx, a->max_n_iter >= 1 && a->max_n_iter <= 1000, "bad max_n_iter");
+    NEED(ctx, !ctx->reduce_fn || (!a->local_p_ref && ctx->opt[PGW_OPT_MULTIPASS] && !ctx->opt[PGW_OPT_FULL_COLUMN]),
+         "a reduce hook (latitude-band sharding) needs the multi-pass loop: fixed p_ref, PGW_OPT_MULTIPASS = 1, "
+         "PGW_OPT_FULL_COLUMN = 0");
     const bool exact = (a->x_hi == 0.0);
     const bool ref = a->ref_dtype != 0;
     NEED(ctx, !ref || dtype == PGW_F32, "ref_dtype = 1 is the float32-file mode: dtype must be PGW_F32");
@@ -1164,8 +1223,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
             HIPCHK(ctx, hipGetLastError());
         }
         if (!defer) {
-            if ((rc = status_check(ctx))) return rc;
-            if ((rc = top_check())) return rc;
+            if ((rc = status_check(ctx))) return band_fail(ctx, rc, a->max_n_iter);
+            if ((rc = top_check())) return band_fail(ctx, rc, a->max_n_iter);
         }
     }
 

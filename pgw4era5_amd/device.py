@@ -146,9 +146,33 @@ class Context:
         self.device = int(device) % n.value
         self._live = 0
         self._levels_key = None
+        self._reduce_cb = None                  # keeps the ctypes callback of set_reduce_hook alive
+        self._reduce_exc = None
 
     def _check(self, rc):
+        if rc == _lib.PGW_ERR_REDUCE and self._reduce_exc is not None:
+            exc, self._reduce_exc = self._reduce_exc, None
+            raise exc                           # what the hook itself raised (e.g. a torch.distributed error)
         _lib.check(self.handle, rc)
+
+    def set_reduce_hook(self, fn):
+        """`pgw_set_reduce_hook`: `fn(vals)` replaces the float64 array `vals` IN PLACE by its element-wise maximum over the ranks that
+        hold the other latitude bands of the file being processed (parallel.band_max_hook); None removes the hook."""
+        if fn is None:
+            self._check(self.lib.pgw_set_reduce_hook(self.handle, _lib.REDUCE_MAX_FN(), None))
+            self._reduce_cb = None
+            return
+
+        def cb(vals, n, _user):
+            try:
+                fn(np.ctypeslib.as_array(vals, shape=(n,)))
+                return 0
+            except BaseException as e:          # noqa: BLE001 - re-raised by _check on the Python side of the call
+                self._reduce_exc = e
+                return 1
+        cfn = _lib.REDUCE_MAX_FN(cb)
+        self._check(self.lib.pgw_set_reduce_hook(self.handle, cfn, None))
+        self._reduce_cb = cfn
 
     def close(self):
         if self.handle:

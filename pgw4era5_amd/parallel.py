@@ -26,6 +26,34 @@ def shard_indices(ntasks, rank, world):
     return list(range(rank, ntasks, world))
 
 
+def band_rows(nlat, rank, world):
+    """Latitude rows [j0, j1) of rank `rank` when ONE file is split over `world` ranks (the
+    latency mode).  Contiguous bands, sizes differing by at most one row; the columns of a file are independent but for
+    the loop's stopping test (step_03_apply_to_era.py:189, 308), which band_max_hook makes global."""
+    base, extra = divmod(int(nlat), int(world))
+    j0 = rank * base + min(rank, extra)
+    return j0, j0 + base + (1 if rank < extra else 0)
+
+
+def band_max_hook(group=None):
+    """The exchange step of the latency mode: element-wise MAX all-reduce of the loop's per-pass figures (at most 25
+    doubles per loop launch) over the ranks of `group` - RCCL when the process group's backend is nccl (the values make
+    one hop through a device tensor), gloo otherwise.  For Context.set_reduce_hook."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = dist.get_backend(group) == 'nccl'
+
+    def hook(vals):
+        t = torch.from_numpy(vals)              # shares memory with `vals`
+        if on_gpu:
+            d = t.cuda()
+            dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+            t.copy_(d)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return hook
+
+
 def _merge(fargs, step_args):
     tasks = []
     for s in step_args:

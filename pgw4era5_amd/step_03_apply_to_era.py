@@ -330,10 +330,38 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     return out, dict(n_iter=it - 1, max_err=hist, levels_touched=0)
 
 
+def _band_of(arrays, j0, j1):
+    """Latitude rows [j0, j1) of every field of a dict (lat is the second-to-last axis; tables such as ak / bk pass through)."""
+    out = {}
+    for k, v in arrays.items():
+        a = np.asarray(v) if v is not None else None
+        out[k] = a[..., j0:j1, :] if (a is not None and a.ndim >= 3) else v
+    return out
+
+
 def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, dtype=None, i_reinterp=False, ref_dtype=None):
-    """Whole-file path on in-memory host arrays (upload, compute on the GPU, download)."""
+                        p_ref=None, dtype=None, i_reinterp=False, ref_dtype=None, band=None, reduce_max=None):
+    """Whole-file path on in-memory host arrays (upload, compute on the GPU, download).
+
+    band = (rank, world): this process handles latitude band `rank` of `world` of the file (parallel.band_rows) and
+    returns that band's rows; `reduce_max` (parallel.band_max_hook) makes the loop's stopping test global, so the bands
+    put together are bit for bit the single-process result, pass count and max|err| history included."""
     ctx = default_context()
+    if band is not None:
+        from .parallel import band_rows
+        if i_reinterp or p_ref == 'local':
+            raise ValueError('latitude-band sharding of one file needs the fixed-p_ref loop (i_reinterp = 0, p_ref_inp set)')
+        if reduce_max is None and band[1] > 1:
+            raise ValueError('band sharding over more than one rank needs reduce_max (parallel.band_max_hook)')
+        j0, j1 = band_rows(np.asarray(era['T']).shape[-2], band[0], band[1])
+        era, deltas = _band_of(era, j0, j1), _band_of(deltas, j0, j1)
+    if reduce_max is not None:
+        ctx.set_reduce_hook(reduce_max)
+        try:
+            return pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error, p_ref, dtype,
+                                       i_reinterp, ref_dtype)
+        finally:
+            ctx.set_reduce_hook(None)
     if dtype is None:
         dtype = np.asarray(era['T']).dtype
     dtype = np.dtype(dtype)

@@ -2,6 +2,8 @@
 synthetic NetCDF-3 files, against the oracle evaluated on the same arrays."""
 import datetime as dt
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +12,7 @@ from oracle import pgw_oracle as O
 from oracle import pgw_oracle_refdtype as R
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
@@ -357,3 +360,89 @@ def test_step02_cli_smoothing(tmp_path):
         np.testing.assert_allclose(res[name].values, O.filter_data_array(sq), rtol=0, atol=2e-6 * np.abs(v).max())
         np.testing.assert_array_equal(res['lat'].values, lat)
         assert res[name].attrs['units'] == 'K'
+
+
+BAND_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import torch                                   # before libpgw_hip.so (pgw4era5_amd/_lib.py)
+import torch.distributed as dist
+from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
+from pgw4era5_amd.parallel import band_max_hook
+os.environ['LOCAL_RANK'] = '0'                 # both ranks on the one GPU of the box
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+out_dir, mode = sys.argv[1], sys.argv[2]
+plev = None
+if mode == 'poison_pshist':                    # deltas reaching above the ERA5 model top: the model-top check passes
+    plev = np.concatenate([synthetic.PLEV19, [0.1]])
+case = synthetic.make_case(nlat=21, nlon=32, nlev=40, seed=11, dtype=np.float64, plev=plev)
+if mode == 'poison_pref':
+    case['era']['PS'][0, 17, 5] = 20000.0       # band 1 only: p_ref = 300 hPa lies below this "surface"
+if mode == 'poison_pshist':
+    case['deltas']['ps_hist'][:, 17, 5] = 0.05  # band 1 only: historical surface pressure above the top delta level
+res = None
+try:
+    for rep in range(2):                       # twice: the second file starts from the first one's pass count (loop_guess)
+        res = s3.pgw_for_era5_arrays(case['era'], case['deltas'], case['delta_times'], case['plev'], case['target_dt'],
+                                     ignore_top_pressure_error=(sys.argv[3] == 't'), band=(rank, world), reduce_max=band_max_hook())
+    np.savez(os.path.join(out_dir, 'band%%d.npz' %% rank), n_iter=res['n_iter'], max_err=np.asarray(res['max_err']),
+             **{k: res[k] for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE')})
+    msg = 'ok'
+except ValueError as e:
+    msg = 'ValueError: ' + str(e)
+with open(os.path.join(out_dir, 'msg%%d.txt' %% rank), 'w') as f:
+    f.write(msg)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_bands(tmp_path, mode, top='t', port='29541'):
+    script = tmp_path / 'band.py'
+    script.write_text(BAND_SCRIPT % ROOT)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', port, str(script), str(tmp_path), mode, top],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return {k: open(str(tmp_path / ('msg%d.txt' % k))).read() for k in (0, 1) if os.path.exists(str(tmp_path / ('msg%d.txt' % k)))}
+
+
+def test_one_file_in_two_latitude_bands_is_bit_identical(tmp_path):
+    """SURVEY.md section 8e, row 2 (latency mode): ONE file split into two latitude bands over two ranks (gloo here, both on
+    the one GPU; RCCL on a node), the loop's stopping test made global by an all-reduce MAX of the per-pass maxima
+    (pgw_set_reduce_hook).  The bands put together must be the single-process result bit for bit - same pass count, same
+    max|err| history (step_03_apply_to_era.py:189, 308: the maximum is over all columns)."""
+    from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
+    from pgw4era5_amd.parallel import band_rows
+    msgs = _run_bands(tmp_path, 'clean')
+    assert msgs == {0: 'ok', 1: 'ok'}
+    case = synthetic.make_case(nlat=21, nlon=32, nlev=40, seed=11, dtype=np.float64)
+    whole = s3.pgw_for_era5_arrays(case['era'], case['deltas'], case['delta_times'], case['plev'], case['target_dt'],
+                                   ignore_top_pressure_error=True)
+    bands = [np.load(str(tmp_path / ('band%d.npz' % r))) for r in range(2)]
+    assert band_rows(21, 0, 2) == (0, 11) and band_rows(21, 1, 2) == (11, 21)
+    for b in bands:
+        assert int(b['n_iter']) == whole['n_iter']
+        np.testing.assert_array_equal(b['max_err'], np.asarray(whole['max_err']))      # the GLOBAL maxima, on both ranks
+    # the two bands' own maxima differ, so a band alone would in general stop elsewhere: the exchange matters
+    for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE'):
+        got = np.concatenate([bands[0][k], bands[1][k]], axis=-2)
+        np.testing.assert_array_equal(got, whole[k], err_msg=k)
+
+
+@pytest.mark.parametrize('mode', ['poison_pref', 'poison_pshist'])
+def test_a_band_that_fails_fails_all_bands(tmp_path, mode):
+    """An error status raised by one band reaches every rank through the same reduce, so all ranks raise the reference's
+    ValueError and none waits for a peer that has left.  poison_pref: p_ref below the surface in a column of band 1, found
+    by the loop's first launch.  poison_pshist: model-top check ON (a host read-back before the loop) and a column of band 1
+    whose historical surface pressure lies above the top delta level (functions.py:360-361, a bare ValueError): band 1
+    fails BEFORE the loop and meets band 0 in its first reduce."""
+    msgs = _run_bands(tmp_path, mode, 't' if mode == 'poison_pref' else 'check', port='29543' if mode == 'poison_pref' else '29545')
+    assert set(msgs) == {0, 1}
+    for r in (0, 1):
+        if mode == 'poison_pref':
+            assert msgs[r].startswith('ValueError: p_ref locally lies below the surface'), msgs
+        else:
+            assert msgs[r] == 'ValueError: ', msgs

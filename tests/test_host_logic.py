@@ -488,3 +488,42 @@ def test_pipelined_shard_overlaps_stages_and_keeps_order():
     func.stages = (load, bad_compute, store)
     with pytest.raises(ValueError):
         run_shard(func, tasks, list(range(6)))
+
+
+BAND_HOOK_SCRIPT = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from pgw4era5_amd.parallel import band_max_hook, band_rows
+dist.init_process_group('gloo')
+r = dist.get_rank()
+hook = band_max_hook()
+v = np.array([0.0, 0.0, 1.0, 0.3 + r, 0.0, float(r), -np.inf if r == 0 else 0.125, 13.0 * r])
+hook(v)                                        # in place
+with open(os.path.join(sys.argv[1], 'hook%%d.json' %% r), 'w') as f:
+    json.dump(v.tolist(), f)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_band_rows_and_band_max_hook_gloo(tmp_path):
+    """Host side of the latency mode (one file in latitude bands): the partition, and the exchange step - an element-wise
+    MAX all-reduce over two gloo ranks, in place on the array the C library hands to the hook."""
+    from pgw4era5_amd.parallel import band_rows
+    for nlat, world in ((721, 8), (21, 2), (5, 5), (7, 3)):
+        rows = [band_rows(nlat, r, world) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == nlat
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in rows]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    script = tmp_path / 'h.py'
+    script.write_text(BAND_HOOK_SCRIPT % ROOT)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29523', str(script), str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    lines = {k: json.load(open(str(tmp_path / ('hook%d.json' % k)))) for k in (0, 1)}
+    assert lines[0] == lines[1] == [0.0, 0.0, 1.0, 1.3, 0.0, 1.0, 0.125, 13.0]
