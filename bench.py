@@ -519,13 +519,17 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
             ctx._check(ctx.lib.pgw_memcpy_d2h(ctx.handle, p, res[k].ptr, n4))      # n4 bytes of each output (all of it unless ref)
         ctx.sync()
     el = (time.perf_counter() - t0) / reps
-    for p in hp:
-        ctx.lib.pgw_host_free(ctx.handle, p)
     out['pcie_inclusive'] = dict(ms_per_file=round(el * 1e3, 2), files_per_hour=round(3600.0 / el, 1),
                                  GB_moved_each_way=round(4 * n4 / 1e9, 3),
                                  note='pinned H2D of T,QV,U,V + path + D2H of T,QV,U,V on one stream')
     for v in res.values():
         v.free()
+    try:
+        out['pcie_inclusive']['pipelined'] = pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4)
+    except Exception as e:                  # noqa: BLE001
+        out['pcie_inclusive']['pipelined'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    for p in hp:
+        ctx.lib.pgw_host_free(ctx.handle, p)
     # step_02 for tos / siconc: 12 months of an ocean-grid delta (802 x 404 curvilinear points, NaN over land) onto the ERA5 grid
     try:
         oc = synthetic.make_ocean_grid_case(nj=404, ni=802, ntime=12, seed=6, land_patches=6)
@@ -554,6 +558,91 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
         except Exception as e:      # noqa: BLE001
             out['end_to_end_cli'] = {'error': '%s: %s' % (type(e).__name__, e)}
     return out
+
+
+def pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4, files=8):
+    """The same host-to-host work as `pcie_inclusive`, organised like the file driver (step_03_apply_to_era.py stages):
+    uploads on the 'h2d' stream, kernels on the context's stream, downloads on the 'd2h' stream, two device buffer sets
+    each way, one host thread per stage - so the upload of file i+1 and the download of file i-1 run during the kernels of
+    file i and PCIe carries both directions at once.  ms per file = wall time of `files` files / files (fill and drain
+    included)."""
+    import ctypes as C
+    import queue
+    import threading
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    up, dn = ctx.side('h2d'), ctx.side('d2h')
+    second = {k: (ctx.empty(v.shape, v.dtype) if k in names else v) for k, v in era.items()}   # small fields: shared, read-only
+    in_sets, out_sets = [era, second], [{}, {}]
+    hout = []
+    for _ in range(4):
+        p = C.c_void_p()
+        ctx._check(ctx.lib.pgw_host_alloc(ctx.handle, n4, C.byref(p)))
+        hout.append(p)
+    for o in out_sets:                       # allocate the outputs outside the timed region
+        s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=o, ref_dtype=ref)
+    ctx.sync()
+    in_free, out_free, q_c, q_d = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+    for i in (0, 1):
+        in_free.put(i); out_free.put(i)
+    errs = []
+
+    def guard(fn):
+        def run():
+            try:
+                fn()
+            except BaseException as e:       # noqa: BLE001
+                errs.append(repr(e))
+                q_c.put(None); q_d.put(None)
+        return run
+
+    def uploader():
+        for _ in range(files):
+            s = in_free.get()
+            for k, p in zip(names, hp):
+                up._check(up.lib.pgw_memcpy_h2d(up.handle, in_sets[s][k].ptr, p, n4))
+            up.sync()
+            q_c.put(s)
+        q_c.put(None)
+
+    def computer():
+        while True:
+            s = q_c.get()
+            if s is None:
+                break
+            o = out_free.get()
+            s3.process_file_device(ctx, in_sets[s], coeffs, deltas, case['target_dt'], True, out=out_sets[o], ref_dtype=ref)
+            ctx.sync()
+            in_free.put(s)
+            q_d.put(o)
+        q_d.put(None)
+
+    def downloader():
+        while True:
+            o = q_d.get()
+            if o is None:
+                break
+            for k, p in zip(names, hout):
+                dn._check(dn.lib.pgw_memcpy_d2h(dn.handle, p, out_sets[o][k].ptr, n4))
+            dn.sync()
+            out_free.put(o)
+    th = [threading.Thread(target=guard(f)) for f in (uploader, computer, downloader)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = (time.perf_counter() - t0) / files
+    for p in hout:
+        ctx.lib.pgw_host_free(ctx.handle, p)
+    for k in names:
+        second[k].free()
+    for o in out_sets:
+        for v in o.values():
+            v.free()
+    if errs:
+        return {'error': errs[0]}
+    return dict(ms_per_file=round(el * 1e3, 2), files_per_hour=round(3600.0 / el, 1), files=files,
+                note='three HIP streams (h2d, kernels, d2h), two device buffer sets each way, one host thread per stage')
 
 
 def f32_storage(ctx, case, coeffs, a, np, steps=5):

@@ -53,18 +53,22 @@ class DeviceArray:
     def ndim(self):
         return len(self.shape)
 
-    def numpy(self):
+    def numpy(self, ctx=None):
+        c = ctx or self.ctx
         out = np.empty(self.shape, dtype=self.dtype)
         if self.nbytes:
-            self.ctx._check(self.ctx.lib.pgw_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes))
-            self.ctx.sync()
+            c._check(c.lib.pgw_memcpy_d2h(c.handle, out.ctypes.data, self.ptr, self.nbytes))
+            c.sync()
         return out
 
-    def copy_from(self, host, sync=True):
+    def copy_from(self, host, sync=True, ctx=None):
         """Upload a host array.  An array in the file's byte order (e.g. '>f4' from `ncio.open_dataset(raw_big=True)`)
         of the same element size is uploaded as it is and converted on the device (`pgw_byteswap`), so the host
         never touches the values.  sync=False: the caller synchronises the context before `host` may be reused
-        (meant for pinned sources, where the copy is a real asynchronous DMA)."""
+        (meant for pinned sources, where the copy is a real asynchronous DMA).  ctx: another context of the same device
+        whose stream carries the transfer (Context.side), so that it overlaps the kernels of this array's own context; the
+        caller orders the two streams (a sync of `ctx` before the array is used)."""
+        c = ctx or self.ctx
         host = np.asarray(host)
         swapped = (host.dtype.byteorder == _FOREIGN and host.dtype.kind == self.dtype.kind
                    and host.dtype.itemsize == self.dtype.itemsize and host.flags.c_contiguous)
@@ -73,24 +77,25 @@ class DeviceArray:
         if host.shape != self.shape:
             raise ValueError('shape mismatch %s vs %s' % (host.shape, self.shape))
         if self.nbytes:
-            self.ctx._check(self.ctx.lib.pgw_memcpy_h2d(self.ctx.handle, self.ptr, host.ctypes.data, self.nbytes))
+            c._check(c.lib.pgw_memcpy_h2d(c.handle, self.ptr, host.ctypes.data, self.nbytes))
             if swapped:
-                self.ctx._check(self.ctx.lib.pgw_byteswap(self.ctx.handle, self.dtype.itemsize, self.size, self.ptr, self.ptr))
+                c._check(c.lib.pgw_byteswap(c.handle, self.dtype.itemsize, self.size, self.ptr, self.ptr))
             if sync:
-                self.ctx.sync()      # pageable source: keep it alive until the copy is done
+                c.sync()             # pageable source: keep it alive until the copy is done
         return self
 
-    def download_foreign(self, host_bytes, scratch=None):
+    def download_foreign(self, host_bytes, scratch=None, ctx=None):
         """Enqueue: convert to the file's (big-endian) byte order on the device - into `scratch` if given, else in
         place, which leaves this array byte-reversed - and copy to the writable uint8 host buffer.  No
         synchronisation: the caller calls `ctx.sync()` before reading `host_bytes`.  Returns the host buffer viewed
-        with the big-endian dtype and this array's shape."""
+        with the big-endian dtype and this array's shape.  ctx: see copy_from."""
+        c = ctx or self.ctx
         if host_bytes.nbytes < self.nbytes:
             raise ValueError('host buffer too small')
         dst = self.ptr if scratch is None else scratch.ptr
         if self.nbytes:
-            self.ctx._check(self.ctx.lib.pgw_byteswap(self.ctx.handle, self.dtype.itemsize, self.size, self.ptr, dst))
-            self.ctx._check(self.ctx.lib.pgw_memcpy_d2h(self.ctx.handle, host_bytes.ctypes.data, dst, self.nbytes))
+            c._check(c.lib.pgw_byteswap(c.handle, self.dtype.itemsize, self.size, self.ptr, dst))
+            c._check(c.lib.pgw_memcpy_d2h(c.handle, host_bytes.ctypes.data, dst, self.nbytes))
         return host_bytes[:self.nbytes].view(self.dtype.newbyteorder(_FOREIGN)).reshape(self.shape)
 
     def view(self, shape):
@@ -147,6 +152,7 @@ class Context:
         self._live = 0
         self._levels_key = None
         self._reduce_cb = None                  # keeps the ctypes callback of set_reduce_hook alive
+        self._side = {}
         self._reduce_exc = None
 
     def _check(self, rc):
@@ -174,7 +180,18 @@ class Context:
         self._check(self.lib.pgw_set_reduce_hook(self.handle, cfn, None))
         self._reduce_cb = cfn
 
+    def side(self, name):
+        """A second context on the same device (its own HIP stream), created on first use: 'h2d' / 'd2h' carry the file
+        transfers of the pipelined driver so that uploads, kernels and downloads of consecutive files overlap (PCIe is
+        full duplex; step_03_apply_to_era.py stages)."""
+        if name not in self._side:
+            self._side[name] = Context(self.device)
+        return self._side[name]
+
     def close(self):
+        for c in self._side.values():
+            c.close()
+        self._side = {}
         if self.handle:
             self.lib.pgw_ctx_destroy(self.handle)
             self.handle = None

@@ -64,50 +64,60 @@ def _merge(fargs, step_args):
 
 
 def run_shard(func, tasks, indices, depth=None, io_threads=None):
-    """Run `func(**tasks[i])` for i in indices on this rank.  If `func.stages = (load, compute,
-    store)` exists, the three stages run as a pipeline: `io_threads` reader threads stay up to
-    `depth` files ahead (host I/O; numpy releases the GIL while it copies / byte-swaps), this thread
-    does the GPU stage in task order, `io_threads` writer threads store results - so file reads and
-    writes overlap the device work and each other (the reference does them serially per worker)."""
+    """Run `func(**tasks[i])` for i in indices on this rank.  If `func.stages = (load, ..., store)` exists (three or more
+    callables, each taking the previous one's result), the stages run as a pipeline over the files: `io_threads` reader
+    threads stay up to `depth` files ahead (host I/O; `pread` and numpy release the GIL), every middle stage has ONE
+    thread and works in task order (pgw_for_era5: upload on the 'h2d' stream, kernels, download on the 'd2h' stream - so
+    the transfers of neighbouring files overlap the kernels and each other, PCIe being full duplex), `io_threads` writer
+    threads store results.  The reference does all of this serially per worker (step_03_apply_to_era.py:44-381).
+    A stage that raises stops the run: `func.abort` (a threading.Event, optional) is set so that stages waiting for a
+    resource give up, and the exception of the earliest failing file is re-raised."""
     stages = getattr(func, 'stages', None)
-    if not stages or len(indices) < 2:
+    if not stages or len(stages) < 3 or len(indices) < 2:
         return [(i, func(**tasks[i])) for i in indices]
     from concurrent.futures import ThreadPoolExecutor
     # stage threads; the NetCDF reader / writer are themselves multi-threaded per file (ncio.py)
     io_threads = int(os.environ.get('PGW_IO_THREADS', '2')) if io_threads is None else io_threads
-    depth = io_threads + 1 if depth is None else depth
-    load, compute, store = stages
-    results = []
-    with ThreadPoolExecutor(max_workers=io_threads) as readers, ThreadPoolExecutor(max_workers=io_threads) as writers:
-        pending = []                                     # load futures, in task order
-        it = iter(indices)
+    depth = io_threads + len(stages) - 2 if depth is None else depth
+    load, middle, store = stages[0], list(stages[1:-1]), stages[-1]
+    abort = getattr(func, 'abort', None)
+    if abort is not None:
+        abort.clear()
+    pools = [ThreadPoolExecutor(max_workers=io_threads)] + [ThreadPoolExecutor(max_workers=1) for _ in middle] + \
+            [ThreadPoolExecutor(max_workers=io_threads)]
+    results, chains = [], []                             # chains: (task index, future of the last stage), in task order
 
-        def top_up():
-            while len(pending) < depth:
-                try:
-                    i = next(it)
-                except StopIteration:
-                    return
-                pending.append((i, readers.submit(load, **tasks[i])))
+    def after(stage, prev):
+        return lambda: stage(prev.result())              # waits for the previous stage of the SAME file (another pool)
 
-        stores = []
-        try:
-            top_up()
-            while pending:
-                i, fut = pending.pop(0)
-                item = fut.result()                      # re-raises a reader's exception
-                top_up()
-                out = compute(item)
-                stores.append((i, writers.submit(store, out)))
-                while len(stores) > depth:               # bound the host memory held by queued outputs
-                    j, f = stores.pop(0)
-                    results.append((j, f.result()))
-            for j, f in stores:
-                results.append((j, f.result()))
-        except BaseException:
-            for _, f in pending:
-                f.cancel()
-            raise
+    def submit(i):
+        fut = pools[0].submit(load, **tasks[i])
+        for k, stage in enumerate(middle):
+            fut = pools[1 + k].submit(after(stage, fut))
+        chains.append((i, pools[-1].submit(after(store, fut))))
+
+    it = iter(indices)
+    try:
+        for _ in range(depth):                           # bound the files in flight (host buffers, device sets)
+            i = next(it, None)
+            if i is None:
+                break
+            submit(i)
+        while chains:
+            j, f = chains.pop(0)
+            results.append((j, f.result()))              # re-raises a stage's exception
+            i = next(it, None)
+            if i is not None:
+                submit(i)
+    except BaseException:
+        if abort is not None:
+            abort.set()
+        for p in pools:
+            p.shutdown(wait=False, cancel_futures=True)
+        raise
+    finally:
+        for p in pools:
+            p.shutdown(wait=True)
     results.sort(key=lambda r: indices.index(r[0]))
     return results
 

@@ -482,46 +482,126 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
                 dims=dict(d3=dims3, d4=dims4, so=dims_so), pinned=pinned)
 
 
+class _BufferSets:
+    """Device buffer sets of one (shape, dtype): `n` input sets and `n` output sets, handed round between the stages.
+    With two sets the upload of file i+1 (stream 'h2d') and the download of file i-1 (stream 'd2h') run while the kernels
+    of file i do - 288 GB of HBM hold many 0.25 deg L137 files (fp64: 4.6 GB in, 4.6 GB out each)."""
+
+    def __init__(self, n):
+        import queue
+        self.inp, self.out = queue.Queue(), queue.Queue()
+        for _ in range(n):
+            self.inp.put({})
+            self.out.put({})
+
+
 _DEVICE_BUFFERS = {}
+_BUFFER_LOCK = __import__('threading').Lock()
+_ABORT = __import__('threading').Event()          # set by parallel.run_shard when a stage failed: waiting stages give up
+
+
+def _buffer_sets(key):
+    with _BUFFER_LOCK:
+        if key not in _DEVICE_BUFFERS:
+            _DEVICE_BUFFERS[key] = _BufferSets(max(1, int(os.environ.get('PGW_DEVICE_SETS', '2'))))
+        return _DEVICE_BUFFERS[key]
+
+
+def _take(q):
+    import queue
+    while True:
+        try:
+            return q.get(timeout=0.2)
+        except queue.Empty:
+            if _ABORT.is_set():
+                raise RuntimeError('pipeline aborted: another stage failed')
+
+
+def _stage_upload(item):
+    """Stage 2 (stream 'h2d'): host -> device copies of one file into a free input buffer set; the file's big-endian
+    bytes are converted on the device."""
+    ctx = default_context()
+    up = ctx.side('h2d')
+    dtype = item['dtype']
+    item['deltas'] = load_delta_set(ctx, item['delta_input_dir'], dtype)
+    sets = _buffer_sets((item['era']['T'].shape, dtype.str))
+    inp = _take(sets.inp)
+    item['sets'], item['inp_set'] = sets, inp
+    try:
+        for k, v in item['era'].items():
+            if k not in inp:
+                inp[k] = ctx.empty(v.shape, dtype)
+            inp[k].copy_from(v, sync=False, ctx=up)
+        up.sync()                                           # the host copies may go, and the compute stream may read
+    except BaseException:
+        sets.inp.put(inp)
+        raise
+    item['era'] = None                                      # release the host copies of the inputs
+    return item
 
 
 def _stage_compute(item):
-    """Stage 2 (GPU): upload, one pgw_step03_file call, download.  Device buffers of a given
-    shape/dtype are reused from file to file."""
-    from . import ncio
+    """Stage 3 (the context's own stream): one pgw_step03_file call on the uploaded buffers into a free output set."""
     ctx = default_context()
-    dtype = item['dtype']
-    deltas = load_delta_set(ctx, item['delta_input_dir'], dtype)
-    key = (item['era']['T'].shape, dtype.str)
-    bufs = _DEVICE_BUFFERS.setdefault(key, dict(inp={}, out={}))
-    for k, v in item['era'].items():
-        if k not in bufs['inp']:
-            bufs['inp'][k] = ctx.empty(v.shape, dtype)
-        bufs['inp'][k].copy_from(v, sync=False)             # host arrays stay alive in `item` until the sync below
+    sets, inp = item['sets'], item['inp_set']
+    try:
+        out_set = _take(sets.out)
+    except BaseException:
+        sets.inp.put(inp)
+        raise
     run = process_file_device_reinterp if S.i_reinterp else process_file_device
     try:
-        out, info = run(ctx, bufs['inp'], item['coeffs'], deltas, item['era_step_dt'], item['ignore_top'],
-                        p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=bufs['out'])
+        out, info = run(ctx, inp, item['coeffs'], item['deltas'], item['era_step_dt'], item['ignore_top'],
+                        p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=out_set)
+        ctx.sync()                                          # outputs complete before the 'd2h' stream reads them
     except ValueError as e:
+        sets.out.put(out_set)
         if getattr(e, 'status', None) == _lib.PGW_ERR_NOT_CONVERGED or str(e).startswith('ERROR! Pressure adjustment did not converge'):
             raise ValueError('ERROR! Pressure adjustment did not converge ' +                   # step_03:315-319, text and file name
                              'for file {}. '.format(item.get('inp_path')) +
                              'Consider increasing the value for "max_n_iter" in ' +
                              'settings.py') from None
         raise
+    except BaseException:
+        sets.out.put(out_set)
+        raise
+    finally:
+        sets.inp.put(inp)                                   # the next upload may overwrite the inputs
+        item['inp_set'] = None
+    item['out_set'], item['out'], item['info'], item['deltas'] = out_set, out, info, None
+    if S.i_debug >= 2:
+        for it, err in enumerate(info['max_err']):
+            print('### iteration {:03d}, phi max error: {}'.format(it + 1, err))
+    return item
+
+
+def _stage_download(item):
+    """Stage 4 (stream 'd2h'): results to the host - the large fields converted to the file's byte order on the device
+    and DMA-ed into pinned buffers the writer `pwrite`s from."""
+    from . import ncio
+    ctx = default_context()
+    dn = ctx.side('d2h')
+    sets, out_set, out = item['sets'], item['out_set'], item['out']
     raw = _io_raw()
     pool = _pinned_pool(ctx) if raw else None
     result, pinned_out = {}, []
-    for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE'):
-        if raw and k in _BIG_OUT and out[k].nbytes >= ncio.BIG_VARIABLE:
-            hb = pool.acquire(out[k].nbytes)
-            pinned_out.append(hb)
-            result[k] = out[k].download_foreign(hb)         # big-endian on the device, DMA into pinned memory
-        else:
-            result[k] = out[k].numpy()
-    ctx.sync()
-    item['result'], item['info'] = result, info
-    item['era'] = None                                      # release the host copies of the inputs
+    try:
+        for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE'):
+            if raw and k in _BIG_OUT and out[k].nbytes >= ncio.BIG_VARIABLE:
+                hb = pool.acquire(out[k].nbytes)
+                pinned_out.append(hb)
+                result[k] = out[k].download_foreign(hb, ctx=dn)  # big-endian on the device, DMA into pinned memory
+            else:
+                result[k] = out[k].numpy(ctx=dn)
+        dn.sync()
+    except BaseException:
+        for b_ in pinned_out:
+            pool.release(b_)
+        raise
+    finally:
+        sets.out.put(out_set)
+        item['out_set'] = item['out'] = None
+    item['result'] = result
     # the four replaced 4-D variables leave the dataset now, so their pinned input buffers can be recycled
     # before the writer gets to this file
     era_file, vm = item['era_file'], S.var_name_map
@@ -538,9 +618,6 @@ def _stage_compute(item):
                     keep.append(b_)
             item['pinned'] = keep
     item['pinned_out'] = pinned_out
-    if S.i_debug >= 2:
-        for it, err in enumerate(info['max_err']):
-            print('### iteration {:03d}, phi max error: {}'.format(it + 1, err))
     return item
 
 
@@ -575,11 +652,12 @@ def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step
     Returns the number of loop passes.  When many files are processed through IterMP the three
     stages below run as a pipeline (read of file i+1 and write of file i-1 overlap the GPU work of
     file i; SURVEY.md section 8 f rank 1)."""
-    return _stage_store(_stage_compute(_stage_load(inp_era_file_path, out_era_file_path, delta_input_dir,
-                                                   era_step_dt, ignore_top_pressure_error, debug_mode)))
+    return _stage_store(_stage_download(_stage_compute(_stage_upload(_stage_load(
+        inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt, ignore_top_pressure_error, debug_mode)))))
 
 
-pgw_for_era5.stages = (_stage_load, _stage_compute, _stage_store)
+pgw_for_era5.stages = (_stage_load, _stage_upload, _stage_compute, _stage_download, _stage_store)
+pgw_for_era5.abort = _ABORT
 
 
 def _cli(argv=None):

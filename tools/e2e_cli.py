@@ -55,17 +55,18 @@ def main():
     s3.load_delta_set(s3.default_context(), os.path.join(a.dir, 'deltas'), np.float32)      # once per run
     t_deltas = time.time() - t0
     done = []
-    load, compute, store = s3.pgw_for_era5.stages
+    stages = s3.pgw_for_era5.stages
+    store = stages[-1]
 
     def store_logged(item):
         out = store(item)
         done.append(time.time())
         return out
-    s3.pgw_for_era5.stages = (load, compute, store_logged)
+    s3.pgw_for_era5.stages = stages[:-1] + (store_logged,)
     t0 = time.time()
     n_iter = s3._cli(argv)
     t_pipe = time.time() - t0
-    s3.pgw_for_era5.stages = (load, compute, store)
+    s3.pgw_for_era5.stages = stages
     done.sort()
     half = len(done) // 2                 # second half of the run: pinned buffers allocated, pipeline full
     steady = (done[-1] - done[half - 1]) / (len(done) - half) if half >= 1 and len(done) > half else None
@@ -74,7 +75,7 @@ def main():
               out_era_file_path=os.path.join(a.dir, 'out', 'serial.nc'), delta_input_dir=os.path.join(a.dir, 'deltas'),
               era_step_dt=first, ignore_top_pressure_error=True)
     t0 = time.time(); item = s3._stage_load(**kw); t_load = time.time() - t0
-    t0 = time.time(); item = s3._stage_compute(item); t_comp = time.time() - t0
+    t0 = time.time(); item = s3._stage_download(s3._stage_compute(s3._stage_upload(item))); t_comp = time.time() - t0
     t0 = time.time(); s3._stage_store(item); t_store = time.time() - t0
     print(json.dumps(dict(files=a.files, file_GB=round(size / 1e9, 3), n_iter=n_iter,
                           setup_write_s=round(t_write, 1), delta_load_s=round(t_deltas, 2),
