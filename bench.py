@@ -259,10 +259,10 @@ def main(argv=None):
     overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a, ref) if (solo and a.overlap_streams > 1) else None
     ctx.profile(False)
     latency = None
-    if world > 1:
+    if dist is not None:                            # N > 1 (and the one-rank RCCL rehearsal, PGW_BENCH_FORCE_DIST=1)
         try:
             latency = latency_mode(ctx, a, rank, world, dist, backend, dtype, ref)
-        except Exception as e:                      # noqa: BLE001 - a side measurement; every rank fails or none (same inputs)
+        except Exception as e:                      # noqa: BLE001 - a side measurement, never costs the headline line
             latency = {'error': '%s: %s' % (type(e).__name__, e)}
     elapsed = reduce(elapsed, 'MAX')
     ranks_seen = int(round(reduce(1.0, 'SUM')))
@@ -360,12 +360,22 @@ def latency_mode(ctx, a, rank, world, dist, backend, dtype, ref, files=6, warmup
     import numpy as np
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
     from pgw4era5_amd.parallel import band_rows, band_max_hook
-    case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1, dtype=dtype)
-    j0, j1 = band_rows(a.nlat, rank, world)
-    era = s3._upload_era(ctx, s3._band_of(case['era'], j0, j1), dtype)
-    deltas = s3.DeltaSet(ctx, s3._band_of(case['deltas'], j0, j1), case['delta_times'], case['plev'], dtype)
-    coeffs = dict(ak=case['era']['ak'], bk=case['era']['bk'], soil1=case['era']['soil1'])
-    stamps = [case['target_dt'] + dt.timedelta(hours=i) for i in range(files + warmup)]
+    dev = 'cuda' if backend == 'nccl' else 'cpu'
+    ready, err = 1.0, None
+    try:
+        case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1, dtype=dtype)
+        j0, j1 = band_rows(a.nlat, rank, world)
+        era = s3._upload_era(ctx, s3._band_of(case['era'], j0, j1), dtype)
+        deltas = s3.DeltaSet(ctx, s3._band_of(case['deltas'], j0, j1), case['delta_times'], case['plev'], dtype)
+        coeffs = dict(ak=case['era']['ak'], bk=case['era']['bk'], soil1=case['era']['soil1'])
+        stamps = [case['target_dt'] + dt.timedelta(hours=i) for i in range(files + warmup)]
+    except Exception as e:                          # noqa: BLE001
+        ready, err = 0.0, e
+    # every rank must enter the band loop or none: its reduces are collective
+    t = torch.tensor([ready], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if float(t.item()) < 1.0:
+        raise RuntimeError('set-up failed on a rank%s' % ('' if err is None else ' (this one: %s: %s)' % (type(err).__name__, err)))
     out, n_iter = {}, []
     ctx.set_reduce_hook(band_max_hook())
     try:
@@ -382,7 +392,7 @@ def latency_mode(ctx, a, rank, world, dist, backend, dtype, ref, files=6, warmup
         el = time.perf_counter() - t0
     finally:
         ctx.set_reduce_hook(None)
-    t = torch.tensor([el], dtype=torch.float64, device='cuda' if backend == 'nccl' else 'cpu')
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     for v in out.values():
         v.free()

@@ -769,6 +769,9 @@ static double max_err_of(pgw_ctx *ctx) {
     return m;
 }
 
+#ifndef QUAD_TPB
+#define QUAD_TPB 128
+#endif
 #ifndef QUAD_U
 #define QUAD_U 2          // levels per software-pipeline chunk of k_delta_quad
 #endif
@@ -1166,8 +1169,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
             {
                 Prof pr(ctx, PGW_K_QUAD_DELTA);
 #define LAUNCH_QUAD(OT, LERP_)                                                                                        \
-                    hipLaunchKernelGGL((k_delta_quad<T, TL, QUAD_U, 128, OT, LERP_, REF>), dim3(nblocks((long long)ntime * ncol, 128)), \
-                                       dim3(128), qlds, ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T,     \
+                    hipLaunchKernelGGL((k_delta_quad<T, TL, QUAD_U, QUAD_TPB, OT, LERP_, REF>), dim3(nblocks((long long)ntime * ncol, QUAD_TPB)), \
+                                       dim3(QUAD_TPB), qlds, ctx->stream, ctx->plev_tab, lv, ntime, ncol, (const T *)a->T,     \
                                        (const T *)a->QV, (const T *)a->U, (const T *)a->V, (const T *)a->PS, dth, ds, ph, \
                                        dwd, check_top, (TL *)a->T_out, (TL *)evap, (TL *)a->hur_pgw_out, (TL *)a->U_out,      \
                                        (TL *)a->V_out, (TL *)a->QV_out, qv_done, ctx->n_pure, ctx->d_status)

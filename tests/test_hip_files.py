@@ -222,6 +222,10 @@ def test_bench_rank_under_torch_distributed_run_with_rccl(tmp_path):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['collective']['backend'] == 'rccl (torch nccl)'
     assert line['collective']['ranks_counted_by_all_reduce'] == 1 and line['value'] > 0
+    # the latency-mode leg ran with its reduce hook on RCCL (one band; the all-reduce goes through a device tensor)
+    lm = line['latency_mode']
+    assert 'error' not in lm, lm
+    assert lm['bands'] == 1 and lm['ms_per_file'] > 0 and lm['exchange'].endswith('rccl')
 
 
 def test_step03_24_hourly_files_two_ranks(tmp_path):

@@ -527,3 +527,83 @@ def test_band_rows_and_band_max_hook_gloo(tmp_path):
     import json
     lines = {k: json.load(open(str(tmp_path / ('hook%d.json' % k)))) for k in (0, 1)}
     assert lines[0] == lines[1] == [0.0, 0.0, 1.0, 1.3, 0.0, 1.0, 0.125, 13.0]
+
+
+def test_five_stage_pipeline_with_bounded_buffer_sets_and_abort():
+    """The file driver's shape (step_03_apply_to_era.py stages: load, upload, compute, download, store): middle stages have one
+    thread each and hand a bounded number of buffer sets round; results keep task order; a failing middle stage sets
+    `func.abort`, stages waiting for a buffer set give up and the first failure is re-raised - nothing hangs."""
+    import queue
+    import threading
+    import time
+    from pgw4era5_amd.parallel import run_shard
+    abort = threading.Event()
+    sets_in, sets_out = queue.Queue(), queue.Queue()
+    for i in range(2):
+        sets_in.put(i); sets_out.put(i)
+    in_use = {'in': 0, 'out': 0, 'max_in': 0, 'max_out': 0}
+    lock = threading.Lock()
+    fail_at = {'x': None}
+
+    def take(q):
+        while True:
+            try:
+                return q.get(timeout=0.05)
+            except queue.Empty:
+                if abort.is_set():
+                    raise RuntimeError('aborted')
+
+    def load(x):
+        time.sleep(0.01)
+        return dict(x=x)
+
+    def upload(item):
+        item['in'] = take(sets_in)
+        with lock:
+            in_use['in'] += 1; in_use['max_in'] = max(in_use['max_in'], in_use['in'])
+        time.sleep(0.02)
+        return item
+
+    def compute(item):
+        try:
+            if item['x'] == fail_at['x']:
+                raise ValueError('boom %d' % item['x'])
+            item['out'] = take(sets_out)
+            with lock:
+                in_use['out'] += 1; in_use['max_out'] = max(in_use['max_out'], in_use['out'])
+            time.sleep(0.01)
+            item['y'] = item['x'] ** 2
+        finally:
+            with lock:
+                in_use['in'] -= 1
+            sets_in.put(item.pop('in'))
+        return item
+
+    def download(item):
+        time.sleep(0.02)
+        with lock:
+            in_use['out'] -= 1
+        sets_out.put(item.pop('out'))
+        return item
+
+    def store(item):
+        time.sleep(0.01)
+        return item['y']
+
+    def func(x):
+        return store(download(compute(upload(load(x)))))
+    func.stages = (load, upload, compute, download, store)
+    func.abort = abort
+    tasks = [dict(x=i) for i in range(12)]
+    t0 = time.time()
+    out = run_shard(func, tasks, list(range(12)))
+    el = time.time() - t0
+    assert out == [(i, i * i) for i in range(12)]
+    assert in_use['max_in'] <= 2 and in_use['max_out'] <= 2 and in_use['max_in'] == 2       # both sets were in flight
+    assert el < 12 * 0.07 * 0.8                                                             # stages overlapped
+    fail_at['x'] = 5
+    t0 = time.time()
+    with pytest.raises(ValueError) as e:
+        run_shard(func, tasks, list(range(12)))
+    assert 'boom 5' in str(e.value) and abort.is_set()
+    assert time.time() - t0 < 10
