@@ -45,6 +45,28 @@ __device__ __forceinline__ void storev(T *__restrict__ p, const double (&in)[V])
     *reinterpret_cast<Pack<T, V> *>(p) = t;
 }
 
+// streaming (non-temporal) forms of loadv / storev, see ld_off_nt below
+template <typename T, int V> struct VecOf { typedef T type __attribute__((ext_vector_type(V))); };
+template <typename T, int V>
+__device__ __forceinline__ void loadv_nt(const T *__restrict__ p, double (&out)[V]) {
+    if constexpr (V == 1) out[0] = (double)__builtin_nontemporal_load(p);
+    else {
+        typename VecOf<T, V>::type t = __builtin_nontemporal_load(reinterpret_cast<const typename VecOf<T, V>::type *>(p));
+#pragma unroll
+        for (int i = 0; i < V; ++i) out[i] = (double)t[i];
+    }
+}
+template <typename T, int V>
+__device__ __forceinline__ void storev_nt(T *__restrict__ p, const double (&in)[V]) {
+    if constexpr (V == 1) __builtin_nontemporal_store((T)in[0], p);
+    else {
+        typename VecOf<T, V>::type t;
+#pragma unroll
+        for (int i = 0; i < V; ++i) t[i] = (T)in[i];
+        __builtin_nontemporal_store(t, reinterpret_cast<typename VecOf<T, V>::type *>(p));
+    }
+}
+
 // ---- addressing with 32-bit byte offsets ---------------------------------------------------
 // `base + (long long)index` makes the compiler carry a 64-bit address per array and lane (two VGPRs and a 64-bit
 // add per access).  When a whole array is smaller than 4 GiB the element can be addressed as uniform base (SGPR
@@ -60,6 +82,18 @@ __device__ __forceinline__ T ld_off(const T *__restrict__ base, O byte_off) {
 template <typename T, typename O>
 __device__ __forceinline__ void st_off(T *__restrict__ base, O byte_off, T v) {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
+// Streaming forms (the `nt` bit of global_load / global_store): data that is touched once per launch - the ERA fields in,
+// the PGW fields out - should not displace what IS re-read (delta records, the loop's rows) from L2 / Infinity Cache, and a
+// mixed read + write stream runs ~10 % faster with them (tools/micro/chunk_pattern.hip: 5.0 -> 5.6 TB/s at 128 threads).
+template <typename T, typename O>
+__device__ __forceinline__ T ld_off_nt(const T *__restrict__ base, O byte_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off));
+}
+template <typename T, typename O>
+__device__ __forceinline__ void st_off_nt(T *__restrict__ base, O byte_off, T v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off));
 }
 
 // first reported code wins (kernels of a stream run in order, so an earlier kernel's error outlives later ones);

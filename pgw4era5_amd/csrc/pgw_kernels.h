@@ -495,14 +495,23 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
     if (hus_out) {
         const int N = lv.nlev;
         long long base = ix.t * N * ncol + ix.c;
+        // e is read for the last time and QV is not read again by this library: streaming loads / stores
 #pragma unroll 4
         for (int l = l_start; l < N; ++l) {            // levels < l_start were written by k_delta_quad
             double e[V], r[V];
+#ifdef FINALIZE_NO_NT
             loadv<TL, V>(evap + base + (long long)l * ncol, e);
+#else
+            loadv_nt<TL, V>(evap + base + (long long)l * ncol, e);
+#endif
             double am = lt.akm[l], bm = lt.bkm[l];
 #pragma unroll
             for (int v = 0; v < V; ++v) r[v] = e_to_q(e[v], am + ps[v] * bm);
+#ifdef FINALIZE_NO_NT
             storev<TL, V>(hus_out + base + (long long)l * ncol, r);
+#else
+            storev_nt<TL, V>(hus_out + base + (long long)l * ncol, r);
+#endif
         }
     }
 }
@@ -1023,6 +1032,21 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
 // TO = storage type of the 4-D outputs.  REF (reference-dtype mode; T = float, TO = double): what numpy's promotion
 // computes on float32 files - RELHUM of the ERA state through the float32 e_sat chain
 // (q_to_rh_f32), float32 record differences in the time interpolation, era (float32) + delta (float64) = float64 outputs.
+#ifndef QUAD_NT
+#define QUAD_NT 1
+#endif
+#if QUAD_NT >= 1
+#define QLD ld_off_nt
+#define QST st_off_nt
+#else
+#define QLD ld_off
+#define QST st_off
+#endif
+#if QUAD_NT >= 2
+#define QST2 st_off_nt
+#else
+#define QST2 st_off
+#endif
 template <typename T, typename TO, int U, int TPB, typename O, bool LERP, bool REF>
 __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                        const T *__restrict__ fT, const T *__restrict__ fQ,
@@ -1173,7 +1197,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             O o = base + (O)(u < N ? u : N - 1) * row;
-            nT[u] = (double)ld_off(fT, o); nQ[u] = (double)ld_off(fQ, o); nU[u] = (double)ld_off(fU, o); nV[u] = (double)ld_off(fV, o);
+            nT[u] = (double)QLD(fT, o); nQ[u] = (double)QLD(fQ, o); nU[u] = (double)QLD(fU, o); nV[u] = (double)QLD(fV, o);
         }
         for (int l0 = 0; l0 < N; l0 += U) {
             double cT[U], cQ[U], cU[U], cV[U];
@@ -1183,7 +1207,7 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     O o = base + (O)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * row;
-                    nT[u] = (double)ld_off(fT, o); nQ[u] = (double)ld_off(fQ, o); nU[u] = (double)ld_off(fU, o); nV[u] = (double)ld_off(fV, o);
+                    nT[u] = (double)QLD(fT, o); nQ[u] = (double)QLD(fQ, o); nU[u] = (double)QLD(fU, o); nV[u] = (double)QLD(fV, o);
                 }
             }
 #pragma unroll
@@ -1252,17 +1276,17 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         }
                     }
                     const O o = obase + (O)l * orow;
-                    st_off(oU, o, (TO)(cU[u] + dc));                               // step_03:170-173
-                    st_off(oV, o, (TO)(cV[u] + dd));
+                    QST(oU, o, (TO)(cU[u] + dc));                                  // step_03:170-173
+                    QST(oV, o, (TO)(cV[u] + dd));
                     double rh_era;                                                 // step_03:91-94
                     if (REF) rh_era = q_to_rh_f32((float)cQ[u], pa, (float)cT[u]);
                     else rh_era = q_to_rh(cQ[u], pa, cT[u]);
                     double ta_pgw = cT[u] + da;
                     double hur_pgw = rh_era + db;
-                    st_off(oT, o, (TO)ta_pgw);
+                    QST2(oT, o, (TO)ta_pgw);
                     double e_pgw = rh_to_e(hur_pgw, ta_pgw);                       // functions.py:123
-                    if (l < n_pure) st_off(oQ, o, (TO)e_to_q(e_pgw, pa));          // pa == akm[l] for every finite ps
-                    else st_off(oE, o, (TO)e_pgw);
+                    if (l < n_pure) QST(oQ, o, (TO)e_to_q(e_pgw, pa));             // pa == akm[l] for every finite ps
+                    else QST2(oE, o, (TO)e_pgw);
                     if (oHur) st_off(oHur, o, (TO)hur_pgw);
                 }
             }
@@ -1397,8 +1421,8 @@ __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, 
     long long f0 = (long long)blockIdx.z * per, f1 = f0 + per < nfield ? f0 + per : nfield;
     T *po = out + (long long)j * nlon_t + (active ? i0 : 0);
     auto store = [&](long long f, const double (&r)[W]) {
-        if (W == 1) po[f * plane_t] = (T)r[0];
-        else storev<T, W>(po + f * plane_t, r);           // W * sizeof(T) aligned: W | nlon_t and W | i0
+        storev_nt<T, W>(po + f * plane_t, r);             // W * sizeof(T) aligned: W | nlon_t and W | i0; streaming: the output
+                                                          // must not push the source planes out of L2
     };
     if (staged) {
         // this thread's source column of the window (threads >= span idle in the latitude pass)
@@ -1927,8 +1951,10 @@ __global__ __launch_bounds__(BLOCK) void k_gauss_interp(long long ntarg, const d
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_byteswap(long long n16, long long n, const uint4 *src, uint4 *dst) {   // may alias
     const long long stride = (long long)gridDim.x * blockDim.x;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
-        uint4 v = src[i];
+        const u4 t = __builtin_nontemporal_load(reinterpret_cast<const u4 *>(src) + i);   // read once, written once
+        uint4 v = make_uint4(t.x, t.y, t.z, t.w);
         if (W == 4) {
             v.x = __builtin_bswap32(v.x); v.y = __builtin_bswap32(v.y);
             v.z = __builtin_bswap32(v.z); v.w = __builtin_bswap32(v.w);
@@ -1937,7 +1963,7 @@ __global__ __launch_bounds__(BLOCK) void k_byteswap(long long n16, long long n, 
             unsigned int c = __builtin_bswap32(v.w), d = __builtin_bswap32(v.z);
             v.x = a; v.y = b; v.z = c; v.w = d;
         }
-        dst[i] = v;
+        { u4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w; __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(dst) + i); }
     }
     // tail elements (n not a multiple of 16 / W) and the unaligned case (n16 == 0): element by element
     const long long done = n16 * (16 / W);

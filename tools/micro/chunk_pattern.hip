@@ -10,7 +10,7 @@
 template <int V>
 struct Vec { double v[V]; };
 
-template <int V, int MODE>   // MODE 0 write, 1 read, 2 copy
+template <int V, int MODE>   // MODE 0 write, 1 read, 2 copy, 3 copy with non-temporal stores, 4 copy with non-temporal loads and stores
 __global__ void k(int nlev, long long ncol, const double *__restrict__ in, double *__restrict__ out, double *sink) {
     long long c = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (c >= ncol) return;
@@ -25,9 +25,16 @@ __global__ void k(int nlev, long long ncol, const double *__restrict__ in, doubl
             Vec<V> r = *reinterpret_cast<const Vec<V> *>(in + (long long)l * ncol + c);
 #pragma unroll
             for (int v = 0; v < V; ++v) acc += r.v[v];
-        } else {
+        } else if (MODE == 2) {
             Vec<V> r = *reinterpret_cast<const Vec<V> *>(in + (long long)l * ncol + c);
             *reinterpret_cast<Vec<V> *>(out + (long long)l * ncol + c) = r;
+        } else {
+            double r[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+                r[v] = MODE == 4 ? __builtin_nontemporal_load(in + (long long)l * ncol + c + v) : in[(long long)l * ncol + c + v];
+#pragma unroll
+            for (int v = 0; v < V; ++v) __builtin_nontemporal_store(r[v], out + (long long)l * ncol + c + v);
         }
     }
     if (MODE == 1 && acc == 12345.678) *sink = acc;
@@ -45,7 +52,7 @@ static void run(const char *name, int tpb, int nlev, long long ncol, const doubl
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-    double gb = (double)nlev * ncol * 8 * (MODE == 2 ? 2 : 1) / 1e9;
+    double gb = (double)nlev * ncol * 8 * (MODE >= 2 ? 2 : 1) / 1e9;
     printf("%-6s V=%d tpb=%4d chunk=%5d B  %.3f ms  %.0f GB/s\n", name, V, tpb, tpb * V * 8, ms, gb / ms * 1e3);
 }
 
@@ -58,5 +65,7 @@ int main() {
     for (int t : tpbs) { run<1, 0>("write", t, nlev, ncol, in, out, sink); run<2, 0>("write", t, nlev, ncol, in, out, sink); }
     for (int t : tpbs) { run<1, 1>("read", t, nlev, ncol, in, out, sink); run<2, 1>("read", t, nlev, ncol, in, out, sink); }
     for (int t : tpbs) { run<1, 2>("copy", t, nlev, ncol, in, out, sink); run<2, 2>("copy", t, nlev, ncol, in, out, sink); }
+    for (int t : tpbs) { run<1, 3>("cp-nts", t, nlev, ncol, in, out, sink); run<2, 3>("cp-nts", t, nlev, ncol, in, out, sink); }
+    for (int t : tpbs) { run<1, 4>("cp-ntb", t, nlev, ncol, in, out, sink); run<2, 4>("cp-ntb", t, nlev, ncol, in, out, sink); }
     return 0;
 }
