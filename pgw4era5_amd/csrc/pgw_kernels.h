@@ -6,6 +6,19 @@
 
 namespace pgw {
 
+// Signature-faithful streaming kernels read and write each element once: streaming (non-temporal) forms (pgw_device.h)
+#ifdef SIG_NO_NT
+#define SIG_LOADV loadv
+#define SIG_STOREV storev
+#define SIG_LD(p) (*(p))
+#define SIG_ST(v, p) (*(p) = (v))
+#else
+#define SIG_LOADV loadv_nt
+#define SIG_STOREV storev_nt
+#define SIG_LD(p) __builtin_nontemporal_load(p)
+#define SIG_ST(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 // Vertical-grid tables of a context, in device memory; every access is wave-uniform
 // (index = level loop counter) so the compiler emits scalar (s_load) reads.
 struct Levels {
@@ -234,9 +247,9 @@ __global__ __launch_bounds__(BLOCK) void k_integ_geopot(int nlev, int ntime, lon
         double p[U][V], t[U][V], q[U][V];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            loadv<T, V>(ph + (long long)(l - u) * ncol, p[u]);
-            loadv<T, V>(pt + (long long)(l - u) * ncol, t[u]);
-            loadv<T, V>(pq + (long long)(l - u) * ncol, q[u]);
+            SIG_LOADV<T, V>(ph + (long long)(l - u) * ncol, p[u]);
+            SIG_LOADV<T, V>(pt + (long long)(l - u) * ncol, t[u]);
+            SIG_LOADV<T, V>(pq + (long long)(l - u) * ncol, q[u]);
         }
         bool above = true;
 #pragma unroll
@@ -257,9 +270,9 @@ __global__ __launch_bounds__(BLOCK) void k_integ_geopot(int nlev, int ntime, lon
     }
     for (; l >= 0; --l) {
         double p[V], t[V], q[V];
-        loadv<T, V>(ph + (long long)l * ncol, p);
-        loadv<T, V>(pt + (long long)l * ncol, t);
-        loadv<T, V>(pq + (long long)l * ncol, q);
+        SIG_LOADV<T, V>(ph + (long long)l * ncol, p);
+        SIG_LOADV<T, V>(pt + (long long)l * ncol, t);
+        SIG_LOADV<T, V>(pq + (long long)l * ncol, q);
 #pragma unroll
         for (int v = 0; v < V; ++v) geo_layer(acc[v], l, CON_RD * (t[v] * (1 + 0.61 * q[v])), p[v], pref[v]);
     }
@@ -560,21 +573,21 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
         xn = (double)pp[ncol]; yn = (double)pv[ncol];                // S >= 2
         if (!logp_in) xn = pgw_log(xn);
         const long long o = (long long)(2 < S ? 2 : S - 1) * ncol;
-        rx = (double)pp[o]; ry = (double)pv[o];
+        rx = (double)SIG_LD(pp + o); ry = (double)SIG_LD(pv + o);
     };
     reset();
     double xprev = -__builtin_inf();
     constexpr int U = 4;            // chunks of 4 target levels: the next chunk's loads are in flight while this one is done
     double nx[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)(u < N ? u : N - 1) * ncol];
+    for (int u = 0; u < U; ++u) nx[u] = (double)SIG_LD(pt + (long long)(u < N ? u : N - 1) * ncol);
     for (int l0 = 0; l0 < N; l0 += U) {
         double cx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cx[u] = nx[u];
         if (l0 + U < N) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) nx[u] = (double)pt[(long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol];
+            for (int u = 0; u < U; ++u) nx[u] = (double)SIG_LD(pt + (long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -591,7 +604,7 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
                     xn = logp_in ? rx : pgw_log(rx); yn = ry;
                     ++j;
                     const long long o = (long long)(j + 2 < S ? j + 2 : S - 1) * ncol;
-                    rx = (double)pp[o]; ry = (double)pv[o];
+                    rx = (double)SIG_LD(pp + o); ry = (double)SIG_LD(pv + o);
                 }
                 bool extrap = false;
                 double x1, y1, x2, y2;
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
                 else if (same) y = y1;                                   // :572-573
                 else y = y1 + (x - x1) * (y2 - y1) / (x2 - x1);          // :575-578
                 if (MODE == 0 && extrap) report(st, 12, flat);           // :564-566
-                po[(long long)l * ncol] = (T)y;
+                SIG_ST((T)y, po + (long long)l * ncol);
                 xprev = (x == x) ? x : __builtin_inf();                  // after a NaN target restart
             }
         }
@@ -1851,7 +1864,7 @@ __global__ __launch_bounds__(BLOCK) void k_harmonic_smooth(int ntime, long long 
     for (int t0 = 0; t0 < ntime; t0 += U) {
         double x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = (double)pi[(long long)(t0 + u < ntime ? t0 + u : ntime - 1) * inner];
+        for (int u = 0; u < U; ++u) x[u] = (double)SIG_LD(pi + (long long)(t0 + u < ntime ? t0 + u : ntime - 1) * inner);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = t0 + u;
@@ -1873,7 +1886,7 @@ __global__ __launch_bounds__(BLOCK) void k_harmonic_smooth(int ntime, long long 
         double h2 = a2 * c2[t] + b2 * s2[t];
         double h3 = a3 * c3[t] + b3 * s3[t];
         double r = ((h1 + h2) + h3) + mean;                              // :739
-        po[(long long)t * inner] = (T)(nan ? __builtin_nan("") : r);     // :695-696
+        SIG_ST((T)(nan ? __builtin_nan("") : r), po + (long long)t * inner);     // :695-696
     }
 }
 
