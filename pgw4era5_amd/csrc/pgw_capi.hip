@@ -1391,15 +1391,26 @@ extern "C" int pgw_regrid_bilinear(pgw_ctx *ctx, int dtype, long long nfield, in
             const int W = (nlon_t % 2 == 0 && ((uintptr_t)out % (2 * sizeof(T))) == 0 && !ctx->opt[PGW_OPT_FORCE_VEC1]) ? 2 : 1;
             const unsigned int bx = nblocks(nlon_t, BLOCK * W);
             long long xy = (long long)bx * nlat_t;
-            long long want = (8192 + xy - 1) / xy;
+#ifndef REGRID_BLOCKS
+#define REGRID_BLOCKS 8192
+#endif
+            long long want = (REGRID_BLOCKS + xy - 1) / xy;
             unsigned int gz = (unsigned int)(want < 1 ? 1 : (want > nfield ? nfield : want));
-            // 4 planes per step (2: 6 % slower, 8: the same); ~8 k blocks (40 k: 14 % slower, one z-slice: 3 % slower)
+#ifndef REGRID_XCD
+#define REGRID_XCD 1
+#endif
+            // z-slices in multiples of 8 where there are planes for it: one XCD per slice group (k_regrid)
+            if (REGRID_XCD && nfield >= 8) gz = (gz + 7u) / 8u * 8u;
+            if (gz > nfield) gz = (unsigned int)nfield;
+            NEED(ctx, xy * gz < (1ll << 31), "regrid: too many blocks");
+            const unsigned int nb = (unsigned int)(xy * gz);
+            // 4 planes per step (2: 6 % slower, 8: the same)
             if (W == 2)
-                hipLaunchKernelGGL((k_regrid<T, 4, 2>), dim3(bx, nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+                hipLaunchKernelGGL((k_regrid<T, 4, 2>), dim3(nb), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, bx, gz, (const T *)src, tb, dpole, (T *)out);
             else
-                hipLaunchKernelGGL((k_regrid<T, 4, 1>), dim3(bx, nlat_t, gz), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
-                                   nlon_s, nlat_t, nlon_t, (const T *)src, tb, dpole, (T *)out);
+                hipLaunchKernelGGL((k_regrid<T, 4, 1>), dim3(nb), dim3(BLOCK), 0, ctx->stream, nfield, nlat_s,
+                                   nlon_s, nlat_t, nlon_t, bx, gz, (const T *)src, tb, dpole, (T *)out);
         });
     }
     HIPCHK(ctx, hipGetLastError());

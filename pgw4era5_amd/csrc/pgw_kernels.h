@@ -302,6 +302,8 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
                                              const double (&pref)[V], int full_column, DevStatus *st, long long c2,
                                              double (&phi_ref)[V], double (&tlow)[V], int &touched) {
     const int N = lv.nlev;
+    // the ERA-state scan (SECOND_IS_Q) reads its rows once per file; the loop passes re-read theirs (keep those cacheable)
+#define SCAN_LOADV(p, o) do { if constexpr (SECOND_IS_Q) loadv_nt<TL, V>(p, o); else loadv<TL, V>(p, o); } while (0)
     GeoAcc acc[V];
     bool mono[V];
     {
@@ -316,8 +318,8 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         int lu = (N - 1 - u) > 0 ? (N - 1 - u) : 0;
-        loadv<TL, V>(pt + (long long)lu * ncol, tn[u]);
-        loadv<TL, V>(pe + (long long)lu * ncol, en[u]);
+        SCAN_LOADV(pt + (long long)lu * ncol, tn[u]);
+        SCAN_LOADV(pe + (long long)lu * ncol, en[u]);
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) tlow[v] = tn[0][v];             // ta at the lowest full level, :303
@@ -331,8 +333,8 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int lu = (l - U - u) > 0 ? (l - U - u) : 0;
-                loadv<TL, V>(pt + (long long)lu * ncol, tn[u]);
-                loadv<TL, V>(pe + (long long)lu * ncol, en[u]);
+                SCAN_LOADV(pt + (long long)lu * ncol, tn[u]);
+                SCAN_LOADV(pe + (long long)lu * ncol, en[u]);
             }
         }
 #pragma unroll
@@ -1379,12 +1381,25 @@ constexpr int REGRID_SPAN = BLOCK;       // one source column per thread
 
 template <typename T, int FU, int W>
 __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, int nlon_s, int nlat_t, int nlon_t,
-                                                  const T *__restrict__ src, RegridTables tb,
+                                                  unsigned int bx, unsigned int gz, const T *__restrict__ src, RegridTables tb,
                                                   const double *__restrict__ pole, T *__restrict__ out) {
     __shared__ double s_y[FU][REGRID_SPAN];
     __shared__ int s_first, s_span;
-    const int i0 = (blockIdx.x * BLOCK + threadIdx.x) * W;      // first target lon of this thread (W | nlon_t when W > 1)
-    const int j = blockIdx.y;                                   // target lat
+    // 1-D grid of bx * nlat_t * gz blocks.  Blocks b and b + 8 run on the same XCD (MI355X_MICROARCH.md, workgroup
+    // dispatch), each XCD with its own L2: with gz a multiple of 8, XCD group b % 8 takes the z-slices g, g + 8, ... so
+    // a source plane is fetched into ONE L2 instead of all eight, and the blocks resident on an XCD together are
+    // neighbours in (x, j) of the same planes.  Speed only; any placement is correct.
+    int bxi, j, bz;
+    {
+        const unsigned int L = blockIdx.x, per_slice = bx * (unsigned int)nlat_t;
+        unsigned int w = L, g = 0;
+        if (gz % 8 == 0) { g = L & 7u; w = L >> 3; }
+        const unsigned int sub = w / per_slice, rem = w - sub * per_slice;
+        bz = (gz % 8 == 0) ? (int)(sub * 8u + g) : (int)sub;
+        j = (int)(rem / bx);                                    // target lat
+        bxi = (int)(rem - (unsigned int)j * bx);
+    }
+    const int i0 = (bxi * BLOCK + threadIdx.x) * W;             // first target lon of this thread (W | nlon_t when W > 1)
     const bool active = i0 < nlon_t;
     const int jl = tb.lat_lo[j], jh = tb.lat_hi[j];
     const double ldx = tb.lat_dx[j], lDx = tb.lat_Dx[j];
@@ -1417,7 +1432,7 @@ __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, 
     __syncthreads();
     const int first = s_first;                            // BLOCK * W if the block has no valid point
     int c0 = 0;
-    if (first < BLOCK * W) c0 = tb.lon_lo[blockIdx.x * BLOCK * W + first];
+    if (first < BLOCK * W) c0 = tb.lon_lo[bxi * BLOCK * W + first];
     int rl[W], rh[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -1430,8 +1445,8 @@ __global__ __launch_bounds__(BLOCK) void k_regrid(long long nfield, int nlat_s, 
     const int span = s_span;
     const bool staged = !lat_oob && span <= REGRID_SPAN;
     // fields of this z-slice
-    long long per = (nfield + gridDim.z - 1) / gridDim.z;
-    long long f0 = (long long)blockIdx.z * per, f1 = f0 + per < nfield ? f0 + per : nfield;
+    long long per = (nfield + gz - 1) / gz;
+    long long f0 = (long long)bz * per, f1 = f0 + per < nfield ? f0 + per : nfield;
     T *po = out + (long long)j * nlon_t + (active ? i0 : 0);
     auto store = [&](long long f, const double (&r)[W]) {
         storev_nt<T, W>(po + f * plane_t, r);             // W * sizeof(T) aligned: W | nlon_t and W | i0; streaming: the output
