@@ -259,7 +259,10 @@ def main(argv=None):
     overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a, ref) if (solo and a.overlap_streams > 1) else None
     ctx.profile(False)
     latency = None
+    bk_host = case['era']['bk']
     if dist is not None:                            # N > 1 (and the one-rank RCCL rehearsal, PGW_BENCH_FORCE_DIST=1)
+        if world > 1:
+            case = None                             # host copy of this rank's file (~15 GB): free it before the shared file is built
         try:
             latency = latency_mode(ctx, a, rank, world, dist, backend, dtype, ref)
         except Exception as e:                      # noqa: BLE001 - a side measurement, never costs the headline line
@@ -273,7 +276,7 @@ def main(argv=None):
         n_iter = [i['n_iter'] for i in infos]
         passes = sum(n_iter)
         lv_per_launch = sum(i['levels_touched'] for i in infos) / max(passes, 1)
-        bk = case['era']['bk']
+        bk = bk_host
         n_pure = 0
         while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
             n_pure += 1

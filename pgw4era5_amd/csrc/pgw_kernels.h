@@ -7,17 +7,9 @@
 namespace pgw {
 
 // Signature-faithful streaming kernels read and write each element once: streaming (non-temporal) forms (pgw_device.h)
-#ifdef SIG_NO_NT
-#define SIG_LOADV loadv
-#define SIG_STOREV storev
-#define SIG_LD(p) (*(p))
-#define SIG_ST(v, p) (*(p) = (v))
-#else
 #define SIG_LOADV loadv_nt
-#define SIG_STOREV storev_nt
 #define SIG_LD(p) __builtin_nontemporal_load(p)
 #define SIG_ST(v, p) __builtin_nontemporal_store((v), (p))
-#endif
 
 // Vertical-grid tables of a context, in device memory; every access is wave-uniform
 // (index = level loop counter) so the compiler emits scalar (s_load) reads.
@@ -352,11 +344,7 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
                         double q = e_to_q(e[u][v], am + ps[v] * bm);                   // :196, :262-266
                         rtv = CON_RD * (t[u][v] * (1 + 0.61 * q));
                     }
-#ifdef PGW_NO_LOG_TABLE
-                    geo_layer<REF, false>(acc[v], lc, rtv, a + ps[v] * b, pref[v], nullptr);
-#else
                     geo_layer<REF, true>(acc[v], lc, rtv, a + ps[v] * b, pref[v], lt.logtab);
-#endif
                 }
                 touched += V;
             }
@@ -514,19 +502,11 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
 #pragma unroll 4
         for (int l = l_start; l < N; ++l) {            // levels < l_start were written by k_delta_quad
             double e[V], r[V];
-#ifdef FINALIZE_NO_NT
-            loadv<TL, V>(evap + base + (long long)l * ncol, e);
-#else
             loadv_nt<TL, V>(evap + base + (long long)l * ncol, e);
-#endif
             double am = lt.akm[l], bm = lt.bkm[l];
 #pragma unroll
             for (int v = 0; v < V; ++v) r[v] = e_to_q(e[v], am + ps[v] * bm);
-#ifdef FINALIZE_NO_NT
-            storev<TL, V>(hus_out + base + (long long)l * ncol, r);
-#else
             storev_nt<TL, V>(hus_out + base + (long long)l * ncol, r);
-#endif
         }
     }
 }
@@ -1047,21 +1027,10 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
 // TO = storage type of the 4-D outputs.  REF (reference-dtype mode; T = float, TO = double): what numpy's promotion
 // computes on float32 files - RELHUM of the ERA state through the float32 e_sat chain
 // (q_to_rh_f32), float32 record differences in the time interpolation, era (float32) + delta (float64) = float64 outputs.
-#ifndef QUAD_NT
-#define QUAD_NT 1
-#endif
-#if QUAD_NT >= 1
+// streaming forms for what this kernel touches once (ERA fields in; U, V and the pure-level QV out); T_pgw and e are re-read by the loop
 #define QLD ld_off_nt
 #define QST st_off_nt
-#else
-#define QLD ld_off
-#define QST st_off
-#endif
-#if QUAD_NT >= 2
-#define QST2 st_off_nt
-#else
 #define QST2 st_off
-#endif
 template <typename T, typename TO, int U, int TPB, typename O, bool LERP, bool REF>
 __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                        const T *__restrict__ fT, const T *__restrict__ fQ,
