@@ -570,6 +570,11 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
             out['end_to_end_cli'] = end_to_end(a)
         except Exception as e:      # noqa: BLE001
             out['end_to_end_cli'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        try:                        # same run with settings.f32_out_dtype = 'float32' (half the download and the file)
+            r = end_to_end(a, 'float32')
+            out['end_to_end_cli_f32_out'] = {k: r[k] for k in ('n_iter', 'steady_state_s_per_file', 'serial_stage_s', 'files_per_hour_one_rank') if k in r}
+        except Exception as e:      # noqa: BLE001
+            out['end_to_end_cli_f32_out'] = {'error': '%s: %s' % (type(e).__name__, e)}
     return out
 
 
@@ -687,14 +692,15 @@ def f32_storage(ctx, case, coeffs, a, np, steps=5):
     return res
 
 
-def end_to_end(a):
+def end_to_end(a, out_dtype='float64'):
     """tools/e2e_cli.py in a child process: K float32 files through the step_03 command line INCLUDING NetCDF-3 read /
-    write (settings.f32_file_mode default: float64 T, QV, U, V out like the reference)."""
+    write (settings.f32_file_mode default; out_dtype 'float64': T, QV, U, V written as float64 like the reference,
+    'float32': settings.f32_out_dtype = 'float32', narrowed on the GPU)."""
     import subprocess
     import tempfile
     d = a.e2e_dir or tempfile.mkdtemp(prefix='pgw_e2e_')
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'e2e_cli.py'), '--files', str(a.e2e_files), '--nlat', str(a.nlat),
-           '--nlon', str(a.nlon), '--nlev', str(a.nlev), '--dir', d]
+           '--nlon', str(a.nlon), '--nlev', str(a.nlev), '--dir', d, '--out-dtype', out_dtype]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
     for ln in reversed(r.stdout.splitlines()):
         if ln.startswith('{'):

@@ -365,6 +365,13 @@ int pgw_gauss_interp(pgw_ctx *ctx, long long ntarg, const double *tx, const doub
  * and converted at HBM speed, and results are converted before the download, so no host pass touches the fields. */
 int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst);
 
+/* dst[i] = (float)src[i], optionally written byte-reversed (big_endian != 0: the NetCDF classic byte order), n elements,
+ * device pointers.  On float32 ERA5 files the reference's `era + delta` promotes T, QV, U, V to float64 and writes them
+ * so (step_03_apply_to_era.py:170-173, 369-378: the output file is twice the input).  With settings.f32_out_dtype =
+ * 'float32' the file driver computes exactly the same float64 fields and narrows them here on the way out - half the
+ * download and half the file; values = the reference's, rounded once to float32.  No reference counterpart. */
+int pgw_narrow_f64_f32(pgw_ctx *ctx, long long n, const double *src, void *dst, int big_endian);
+
 /* diagnostic: out[i] = ln(in[i]) with the device logarithm every kernel uses (pgw_device.h
  * pgw_log: fdlibm log kernel for positive normal finite x, ocml log otherwise); device fp64 arrays */
 int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out);

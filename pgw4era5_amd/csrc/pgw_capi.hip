@@ -1323,6 +1323,24 @@ extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const voi
     return PGW_OK;
 }
 
+extern "C" int pgw_narrow_f64_f32(pgw_ctx *ctx, long long n, const double *src, void *dst, int big_endian) {
+    NEED(ctx, n >= 0 && (n == 0 || (src && dst)), "bad argument");
+    if (n == 0) return PGW_OK;
+    NEED(ctx, ((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 4) == 0, "pointers must be element-aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool al = ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0;
+    const long long n2 = al ? n / 2 : 0;
+    unsigned int nb = nblocks(n2 ? n2 : n, BLOCK);
+    if (nb > 256 * 16) nb = 256 * 16;
+    {
+        Prof pr(ctx, PGW_K_BYTESWAP);
+        if (big_endian) hipLaunchKernelGGL((k_narrow_f64_f32<true>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n2, n, src, (unsigned int *)dst);
+        else hipLaunchKernelGGL((k_narrow_f64_f32<false>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n2, n, src, (unsigned int *)dst);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 extern "C" int pgw_test_log(pgw_ctx *ctx, long long n, const double *in, double *out) {
     NEED(ctx, n >= 1 && in && out, "bad argument");
     hipLaunchKernelGGL(k_test_log, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out, 0);

@@ -1943,6 +1943,25 @@ __global__ __launch_bounds__(BLOCK) void k_gauss_interp(long long ntarg, const d
     }
 }
 
+// float64 -> float32 (round to nearest even, the conversion numpy's astype does), two elements per lane, optionally byte-reversed
+template <bool SWAP>
+__global__ __launch_bounds__(BLOCK) void k_narrow_f64_f32(long long n2, long long n, const double *__restrict__ src, unsigned int *__restrict__ dst) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const d2 v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src) + i);
+        u2 o;
+        o.x = __float_as_uint((float)v.x); o.y = __float_as_uint((float)v.y);
+        if (SWAP) { o.x = __builtin_bswap32(o.x); o.y = __builtin_bswap32(o.y); }
+        __builtin_nontemporal_store(o, reinterpret_cast<u2 *>(dst) + i);
+    }
+    for (long long e = 2 * n2 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        unsigned int o = __float_as_uint((float)src[e]);
+        dst[e] = SWAP ? __builtin_bswap32(o) : o;
+    }
+}
+
 // Byte-order conversion of a field (NetCDF classic data are big-endian): every 4- or 8-byte element of `src` is
 // written byte-reversed to `dst` (in place allowed), 16 B per lane, grid-stride.  HBM-bound: 2 x n x W bytes.
 template <int W>

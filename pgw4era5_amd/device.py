@@ -98,6 +98,21 @@ class DeviceArray:
             c._check(c.lib.pgw_memcpy_d2h(c.handle, host_bytes.ctypes.data, dst, self.nbytes))
         return host_bytes[:self.nbytes].view(self.dtype.newbyteorder(_FOREIGN)).reshape(self.shape)
 
+    def download_narrow_f32(self, host_bytes, scratch, big_endian=True, ctx=None):
+        """Enqueue: this float64 array -> float32 (`pgw_narrow_f64_f32`, in the file's byte order if big_endian) into the float32
+        device array `scratch`, then copy to the uint8 host buffer.  No synchronisation (see download_foreign).  Returns the
+        host buffer viewed as float32 of this array's shape."""
+        c = ctx or self.ctx
+        if self.dtype != np.dtype('float64') or scratch.dtype != np.dtype('float32') or scratch.size != self.size:
+            raise ValueError('download_narrow_f32: float64 source and a float32 scratch of the same size')
+        if host_bytes.nbytes < scratch.nbytes:
+            raise ValueError('host buffer too small')
+        if self.nbytes:
+            c._check(c.lib.pgw_narrow_f64_f32(c.handle, self.size, self.ptr, scratch.ptr, 1 if big_endian else 0))
+            c._check(c.lib.pgw_memcpy_d2h(c.handle, host_bytes.ctypes.data, scratch.ptr, scratch.nbytes))
+        dt = np.dtype('float32').newbyteorder(_FOREIGN) if big_endian else np.dtype('float32')
+        return host_bytes[:scratch.nbytes].view(dt).reshape(self.shape)
+
     def view(self, shape):
         """Reshaped alias of the same buffer."""
         shape = tuple(int(s) for s in shape)

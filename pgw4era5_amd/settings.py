@@ -40,3 +40,9 @@ i_reinterp = 0
 # 'fast': float64 arithmetic on the stored float32 values, float32 outputs (half the output bytes); PS then differs from
 #     the reference by a few 1e-7 relative and, when the last pass ends within ~0.03 m2/s2 of the threshold, by one pass.
 f32_file_mode = 'reference'
+
+# Output dtype of T, QV, U, V on float32 files in 'reference' mode.  'float64': what the reference writes (`era + delta`
+# promotes; the output file is twice the input).  'float32': the same float64 fields, narrowed on the GPU on the way out -
+# half the download and half the file written (file I/O is what bounds the end-to-end rate); PS and the pass count are the
+# reference's either way.
+f32_out_dtype = 'float64'

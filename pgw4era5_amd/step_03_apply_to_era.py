@@ -439,6 +439,8 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
     if debug_mode is not None:
         raise NotImplementedError('debug_mode (step_03_apply_to_era.py:350-361, 387-414) is a validation aid of '
                                   'the reference and not part of the MI355X hot path')
+    if S.f32_out_dtype not in ('float64', 'float32'):                  # checked before any buffer is taken
+        raise ValueError("settings.f32_out_dtype must be 'float64' or 'float32'")
     if S.i_debug >= 0:
         print('Start working on input file {}'.format(inp_era_file_path))
     raw = _io_raw()
@@ -508,13 +510,20 @@ def _buffer_sets(key):
 
 
 def _take(q):
+    """A free buffer set.  Gives up when another stage has failed (_ABORT) and - so that a set lost to a bug can never hang
+    a run - after PGW_BUFFER_WAIT_S seconds (default 600; a stage of a 0.25 deg file takes well under a second)."""
     import queue
+    import time
+    t0 = time.time()
+    limit = float(os.environ.get('PGW_BUFFER_WAIT_S', '600'))
     while True:
         try:
             return q.get(timeout=0.2)
         except queue.Empty:
             if _ABORT.is_set():
                 raise RuntimeError('pipeline aborted: another stage failed')
+            if time.time() - t0 > limit:
+                raise RuntimeError('no device buffer set became free within %.0f s (PGW_BUFFER_WAIT_S)' % limit)
 
 
 def _stage_upload(item):
@@ -585,14 +594,28 @@ def _stage_download(item):
     raw = _io_raw()
     pool = _pinned_pool(ctx) if raw else None
     result, pinned_out = {}, []
+    # settings.f32_out_dtype = 'float32': the float64 T, QV, U, V of a float32 file leave the device as float32
+    narrow = (S.f32_out_dtype == 'float32' and item['dtype'] == np.dtype('float32'))
     try:
         for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE'):
-            if raw and k in _BIG_OUT and out[k].nbytes >= ncio.BIG_VARIABLE:
-                hb = pool.acquire(out[k].nbytes)
+            o = out[k]
+            if narrow and k in _BIG_OUT and o.dtype == np.dtype('float64'):
+                sk = '_f32_' + k
+                if sk not in out_set or out_set[sk].size != o.size:
+                    out_set[sk] = ctx.empty(o.shape, np.float32)
+                if raw and out_set[sk].nbytes >= ncio.BIG_VARIABLE:
+                    hb = pool.acquire(out_set[sk].nbytes)
+                    pinned_out.append(hb)
+                    result[k] = o.download_narrow_f32(hb, out_set[sk], big_endian=True, ctx=dn)
+                else:
+                    hb = np.empty(out_set[sk].nbytes, dtype=np.uint8)
+                    result[k] = o.download_narrow_f32(hb, out_set[sk], big_endian=False, ctx=dn)
+            elif raw and k in _BIG_OUT and o.nbytes >= ncio.BIG_VARIABLE:
+                hb = pool.acquire(o.nbytes)
                 pinned_out.append(hb)
-                result[k] = out[k].download_foreign(hb, ctx=dn)  # big-endian on the device, DMA into pinned memory
+                result[k] = o.download_foreign(hb, ctx=dn)      # big-endian on the device, DMA into pinned memory
             else:
-                result[k] = out[k].numpy(ctx=dn)
+                result[k] = o.numpy(ctx=dn)
         dn.sync()
     except BaseException:
         for b_ in pinned_out:

@@ -329,6 +329,37 @@ def test_step03_cli_raw_io_path_is_byte_identical(files, monkeypatch):
         assert open(root / 'out_raw' / name, 'rb').read() == open(root / 'out_host' / name, 'rb').read()
 
 
+@pytest.mark.parametrize('raw', ['1', '0'])
+def test_step03_float32_outputs_are_the_reference_fields_rounded_once(files, monkeypatch, raw):
+    """settings.f32_out_dtype = 'float32': same arithmetic as the reference-dtype mode (pass count, PS, the float64 T, QV, U, V
+    on the device), but the four 4-D fields are narrowed on the GPU on the way out: the file holds float32 variables that
+    equal the default mode's float64 variables cast to float32, everything else is byte for byte the default file's -
+    through the pinned raw path (device-side byte order) and the host path."""
+    from pgw4era5_amd import step_03_apply_to_era as s3, ncio, settings as S
+    root, cases = files
+    monkeypatch.setattr(ncio, 'BIG_VARIABLE', 1024)
+    monkeypatch.setenv('PGW_IO_RAW', raw)
+    args = ['-i', str(root / 'era'), '-d', str(root / 'deltas'), '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '1', '-t']
+    n64 = s3._cli(args + ['-o', str(root / ('out64_' + raw))])
+    monkeypatch.setattr(S, 'f32_out_dtype', 'float32')
+    n32 = s3._cli(args + ['-o', str(root / ('out32_' + raw))])
+    assert n64 == n32
+    for c in cases:
+        name = 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])
+        a = ncio.open_dataset(str(root / ('out64_' + raw) / name), decode_times=False)
+        b = ncio.open_dataset(str(root / ('out32_' + raw) / name), decode_times=False)
+        for v in ('T', 'QV', 'U', 'V'):
+            assert a[v].dtype == np.float64 and b[v].dtype == np.float32
+            np.testing.assert_array_equal(b[v].values, a[v].values.astype(np.float32))
+        for v in ('PS', 'T_SKIN', 'T_SO', 'FR_SEA_ICE', 'FIS', 'FR_LAND', 'ak', 'bk'):
+            assert a[v].dtype == b[v].dtype
+            np.testing.assert_array_equal(a[v].values, b[v].values)
+        assert os.path.getsize(str(root / ('out32_' + raw) / name)) < 0.62 * os.path.getsize(str(root / ('out64_' + raw) / name))
+    monkeypatch.setattr(S, 'f32_out_dtype', 'float16')
+    with pytest.raises(ValueError):
+        s3._cli(args + ['-o', str(root / 'out_bad')])
+
+
 def test_step02_cli_smoothing(tmp_path):
     """`step_02 smoothing`: daily delta files in, smoothed files out (size-1 dimensions squeezed like the
     reference's `.squeeze()`, coordinates kept), against the oracle."""

@@ -25,11 +25,14 @@ def main():
     p.add_argument('--nlon', type=int, default=1440)
     p.add_argument('--nlev', type=int, default=137)
     p.add_argument('--dir', default='/tmp/pgw_e2e')
+    p.add_argument('--out-dtype', choices=['float64', 'float32'], default='float64',
+                   help="settings.f32_out_dtype: T, QV, U, V of the float32 files written as float64 (the reference) or narrowed to float32")
     p.add_argument('--ranks', type=int, default=1, help='worker processes (-p); > 1: only the pipelined total is timed')
     a = p.parse_args()
     import numpy as np
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3, settings as S
     S.i_debug = 0
+    S.f32_out_dtype = a.out_dtype
     shutil.rmtree(a.dir, ignore_errors=True)
     t0 = time.time()
     case = synthetic.make_case(a.nlat, a.nlon, a.nlev, seed=1, dtype=np.float32)
