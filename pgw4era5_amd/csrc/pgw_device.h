@@ -129,6 +129,13 @@ struct SharedDivisor {
     }
 };
 
+// n / d by the same steps for a divisor used once: the compiler's IEEE fp64 division without v_div_scale (x2) and
+// v_div_fixup - 8 instead of 11 instructions, the correctly rounded quotient (the same bits) whenever neither operand
+// needs scaling and d is finite and non-zero; used where the divisor is a physical quantity of known range
+// (a temperature offset, a pressure minus a vapour-pressure fraction, 0.622 + 0.378 q, e_sat).  NaN operands give
+// NaN like the division; d = 0 or inf gives NaN where the division gives inf / 0.
+__device__ __forceinline__ double div_ns(double n, double d) { return SharedDivisor(d).divide(n); }
+
 // ---- natural logarithm ------------------------------------------------------------------
 // Every kernel on the path takes one ln(p) per level and column, and with fp64 vector math at
 // half rate the generic ocml log (~65 instructions, double-double internals, denormal /
@@ -265,7 +272,7 @@ __device__ __forceinline__ double pgw_exp(double x) {
 
 // ---- humidity thermodynamics (functions.py:58-125), operation order as written there ----
 __device__ __forceinline__ double esat_water(double ta) {   // :74-89 water
-    return 611.21 * pgw_exp(17.502 * (ta - 273.16) / (ta - 32.19));
+    return 611.21 * pgw_exp(div_ns(17.502 * (ta - 273.16), ta - 32.19));
 }
 __device__ __forceinline__ double esat_ice(double ta) {     // :74-89 ice (a4 = -0.7)
     return 611.21 * pgw_exp(22.587 * (ta - 273.16) / (ta - (-0.7)));
@@ -282,12 +289,14 @@ __device__ __forceinline__ double esat_mixed(double ta) {
     const bool warm = (ta >= T0);
     const double a3 = warm ? 17.502 : 22.587;
     const double a4 = warm ? 32.19 : -0.7;
-    double e1 = 611.21 * pgw_exp(a3 * (ta - T0) / (ta - a4));    // e_w if warm else e_i (NaN for NaN ta)
+    double e1 = 611.21 * pgw_exp(div_ns(a3 * (ta - T0), ta - a4));   // e_w if warm else e_i (NaN for NaN ta)
     if (warm) return e1;
     if (ta <= Ti) {
         if (__builtin_expect(!(ta > 40.0), 0)) {                 // unphysical cold: literal expression, 0*e_w may be NaN/inf
-            double ew = esat_water(no_speculate(ta));
-            return 0.0 * ew + 1.0 * e1;
+            const double t = no_speculate(ta);                  // the literal expressions, IEEE divisions (a divisor may be 0 here)
+            const double ew = 611.21 * pgw_exp(17.502 * (t - 273.16) / (t - 32.19));
+            const double ei = 611.21 * pgw_exp(22.587 * (t - 273.16) / (t - (-0.7)));
+            return 0.0 * ew + 1.0 * ei;
         }
         return e1;
     }
@@ -300,13 +309,13 @@ __device__ __forceinline__ double esat_mixed(double ta) {
     return __builtin_nan("");                                    // NaN temperature
 }
 __device__ __forceinline__ double q_to_e(double hus, double pa) {          // :58-64
-    return hus * pa / (CON_MW_MD + 0.378 * hus);
+    return div_ns(hus * pa, CON_MW_MD + 0.378 * hus);
 }
 __device__ __forceinline__ double e_to_q(double vapp, double pa) {         // :66-72
     return CON_MW_MD * vapp / (pa - (1 - CON_MW_MD) * vapp);
 }
 __device__ __forceinline__ double q_to_rh(double hus, double pa, double ta) {   // :107-116
-    return (q_to_e(hus, pa) / esat_mixed(ta)) * 100;
+    return div_ns(q_to_e(hus, pa), esat_mixed(ta)) * 100;
 }
 // ---- reference-dtype mode: RELHUM of a float32 ERA state as numpy's promotion evaluates functions.py:58-116 ----
 // e_sat of a float32 temperature is float32 throughout (alpha = full_like(ta): :95-98; a1*np.exp(a3*(ta-T0)/(ta-a4)):

@@ -341,7 +341,12 @@ __device__ __forceinline__ void scan_columns(const Levels &lv, const LevTab &lt,
                         if (REF) rtv = rd_tv_f32(t[u][v], e[u][v]);                    // float32 T, QV: float32 products
                         else rtv = CON_RD * (t[u][v] * (1 + 0.61 * e[u][v]));          // functions.py:144
                     } else {
-                        double q = e_to_q(e[u][v], am + ps[v] * bm);                   // :196, :262-266
+                        // e_to_q (:196, :262-266) with the quotient formed like SharedDivisor's: reciprocal, two Newton steps,
+                        // product, one residual correction - the compiler's IEEE sequence without v_div_scale / v_div_fixup
+                        // (3 of its 11 instructions), the same bits for every divisor that needs no scaling (here: a pressure
+                        // minus a fraction of a vapour pressure, 1e-4 .. 1.1e5 Pa)
+                        const double pm = am + ps[v] * bm;
+                        double q = SharedDivisor(pm - (1 - CON_MW_MD) * e[u][v]).divide(CON_MW_MD * e[u][v]);
                         rtv = CON_RD * (t[u][v] * (1 + 0.61 * q));
                     }
                     geo_layer<REF, true>(acc[v], lc, rtv, a + ps[v] * b, pref[v], lt.logtab);
