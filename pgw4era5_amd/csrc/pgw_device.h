@@ -302,7 +302,10 @@ __device__ __forceinline__ double esat_mixed(double ta) {
     }
     if (ta < T0 && ta > Ti) {                                    // mixed phase
         double ew = esat_water(no_speculate(ta));
-        double r = (ta - Ti) / (T0 - Ti);
+        // (ta - Ti) / (T0 - Ti): T0 - Ti = 273.16 - 250.16 = 0x1.7000000000008p+4 in double (not 23); with the double nearest to
+        // its reciprocal the two-step quotient is the correctly rounded one (Markstein), i.e. the bits of the division
+        static_assert(273.16 - 250.16 == 0x1.7000000000008p+4, "T0 - Ti");
+        double r = SharedDivisor(0x1.7000000000008p+4, 0x1.642c8590b215cp-5).divide(ta - Ti);
         double alpha = r * r;                                    // np.power(x, 2.) == x*x
         return alpha * ew + (1 - alpha) * e1;
     }
