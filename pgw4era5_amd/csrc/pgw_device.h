@@ -223,10 +223,12 @@ __device__ __forceinline__ double pgw_log_tab(double x, const double *tab) {
     const unsigned int hi = (unsigned int)__double2hiint(x);
     const unsigned int thi = hi - 0x3FE60000u;                      // (bits(x) - OFF) >> 32; OFF's low word is 0: no borrow
     // positive normal finite x  <=>  0x00100000 <= hi < 0x7FF00000
-    if (__builtin_expect(!(hi - 0x00100000u < 0x7FE00000u), 0)) return log(no_speculate(x));
     const int i = (int)((thi >> 13) & 127u);
     const int k = (int)thi >> 20;
-    if (__builtin_expect(k == 0 && (i == 79 || i == 80), 0)) return pgw_log_impl<true, true>(no_speculate(x));
+    // one divergent region for both exceptions: not a positive normal finite number (library log), or within two table
+    // intervals of 1, where r = z/c - 1 cancels (fdlibm kernel; pgw_log_impl sends non-normal arguments to the library itself)
+    if (__builtin_expect(!(hi - 0x00100000u < 0x7FE00000u) || (k == 0 && (i == 79 || i == 80)), 0))
+        return pgw_log_impl<true, true>(no_speculate(x));
     const double z = __hiloint2double((int)(hi - (thi & 0xFFF00000u)), __double2loint(x));
     const double invc = tab[2 * i], logc = tab[2 * i + 1];
     const double r = __builtin_fma(z, invc, -1.0);
@@ -284,24 +286,11 @@ __device__ __forceinline__ double esat_ice(double ta) {     // :74-89 ice (a4 = 
 // One unconditional division + exp evaluates the phase every temperature needs (water for
 // T >= T0, ice otherwise; the coefficients are selected, not the results), and only lanes in the
 // mixed range take a real branch (no_speculate) for the second one.
-__device__ __forceinline__ double esat_mixed(double ta) {
+// the temperatures the one-exponential value does not serve: mixed phase, unphysically cold, NaN
+__device__ __forceinline__ double esat_special(double ta, double e1) {
     const double T0 = 273.16, Ti = 250.16;
-    const bool warm = (ta >= T0);
-    const double a3 = warm ? 17.502 : 22.587;
-    const double a4 = warm ? 32.19 : -0.7;
-    double e1 = 611.21 * pgw_exp(div_ns(a3 * (ta - T0), ta - a4));   // e_w if warm else e_i (NaN for NaN ta)
-    if (warm) return e1;
-    if (ta <= Ti) {
-        if (__builtin_expect(!(ta > 40.0), 0)) {                 // unphysical cold: literal expression, 0*e_w may be NaN/inf
-            const double t = no_speculate(ta);                  // the literal expressions, IEEE divisions (a divisor may be 0 here)
-            const double ew = 611.21 * pgw_exp(17.502 * (t - 273.16) / (t - 32.19));
-            const double ei = 611.21 * pgw_exp(22.587 * (t - 273.16) / (t - (-0.7)));
-            return 0.0 * ew + 1.0 * ei;
-        }
-        return e1;
-    }
     if (ta < T0 && ta > Ti) {                                    // mixed phase
-        double ew = esat_water(no_speculate(ta));
+        double ew = esat_water(ta);
         // (ta - Ti) / (T0 - Ti): T0 - Ti = 273.16 - 250.16 = 0x1.7000000000008p+4 in double (not 23); with the double nearest to
         // its reciprocal the two-step quotient is the correctly rounded one (Markstein), i.e. the bits of the division
         static_assert(273.16 - 250.16 == 0x1.7000000000008p+4, "T0 - Ti");
@@ -309,7 +298,24 @@ __device__ __forceinline__ double esat_mixed(double ta) {
         double alpha = r * r;                                    // np.power(x, 2.) == x*x
         return alpha * ew + (1 - alpha) * e1;
     }
+    if (ta <= 40.0) {                                            // unphysical cold: the literal expression, 0 * e_w may be NaN / inf
+        const double ew = 611.21 * pgw_exp(17.502 * (ta - 273.16) / (ta - 32.19));     // IEEE division: the divisor is 0 at 32.19 K
+        // e1 is e_i here; its scale-free division differs from the IEEE one only where ta + 0.7 == 0: exp(-inf) = 0
+        const double ei = (ta == -0.7) ? 0.0 : e1;
+        return 0.0 * ew + 1.0 * ei;
+    }
     return __builtin_nan("");                                    // NaN temperature
+}
+__device__ __forceinline__ double esat_mixed(double ta) {
+    const double T0 = 273.16, Ti = 250.16;
+    const bool warm = (ta >= T0);
+    const double a3 = warm ? 17.502 : 22.587;
+    const double a4 = warm ? 32.19 : -0.7;
+    double e1 = 611.21 * pgw_exp(div_ns(a3 * (ta - T0), ta - a4));   // e_w if warm else e_i (NaN for NaN ta)
+    // ONE divergent region per call (every branch costs scalar instructions and issue slots the few resident waves of the
+    // delta kernels cannot hide): e1 is the answer for T >= T0 and for 40 K < T <= Ti
+    if (__builtin_expect(!(warm || (ta <= Ti && ta > 40.0)), 0)) e1 = esat_special(no_speculate(ta), e1);
+    return e1;
 }
 __device__ __forceinline__ double q_to_e(double hus, double pa) {          // :58-64
     return div_ns(hus * pa, CON_MW_MD + 0.378 * hus);
