@@ -885,16 +885,18 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     const int full_column = ctx->opt[PGW_OPT_FULL_COLUMN];
     const bool local = local_nplev > 0;
     // several passes per launch: fixed p_ref, wave-level early exit (the full-column option is a per-pass traffic probe)
-    const bool multipass = !local && ctx->opt[PGW_OPT_MULTIPASS] && !full_column;
-    NEED(ctx, !ctx->reduce_fn || multipass, "a reduce hook (latitude-band sharding) needs the multi-pass loop: fixed p_ref, "
-                                            "PGW_OPT_MULTIPASS = 1, PGW_OPT_FULL_COLUMN = 0");
+    const bool multipass = ctx->opt[PGW_OPT_MULTIPASS] && !full_column;
+    NEED(ctx, !ctx->reduce_fn || (multipass && !local), "a reduce hook (latitude-band sharding) needs the multi-pass loop: fixed p_ref, "
+                                                         "PGW_OPT_MULTIPASS = 1, PGW_OPT_FULL_COLUMN = 0");
     PlevTable ptf;
     memset(&ptf, 0, sizeof(ptf));
+    if (local) {
+        ptf.n = local_nplev;
+        for (int i = 0; i < local_nplev; ++i) ptf.p[i] = plev_file[i];
+    }
     if (multipass) {
         // phi_ref of the ERA state, g * dzg and the zeroed state are produced by the first k_ps_loop_multi launch
     } else if (local) {
-        ptf.n = local_nplev;
-        for (int i = 0; i < local_nplev; ++i) ptf.p[i] = plev_file[i];
         HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
     } else {
         // phi_ref_era: constant over the iterations for a fixed p_ref (step_03:280-287 recomputes it).
@@ -945,12 +947,19 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                 int vec = pick_vec(ctx, dtype, ncol, {ta_pgw, evap, era_T, era_QV, PS, FIS, phi_era, dphi, delta_ps, adj_ps, dps_hist}, MULTI_MAXV);
                 Levels lv = levels_of(ctx);
                 Prof pr(ctx, PGW_K_PS_LOOP_MULTI);
+                const LocalPRef loc{ptf, ctx->h_akN, ctx->h_bkN, pref_f, pref_idx};
                 DISPATCH_TLV(dtype, ref, vec, {
                     DeltaSrc<T> z{(const T *)dzg_b, (x_hi == 0.0) ? nullptr : (const T *)dzg_a, x_hi, x_new};
-                    hipLaunchKernelGGL((k_ps_loop_multi<T, TL, V, STEP_U, REF>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0, ctx->stream,
-                                       lv, ntime, ncol, (const T *)era_T, (const T *)era_QV, (const TL *)ta_pgw, (const TL *)evap,
-                                       (const T *)PS, (const T *)FIS, z, phi_era, dphi, delta_ps, adj_ps, dps_hist, p_ref,
-                                       adj_factor, first ? 1 : 0, np, ctx->d_status, mst);
+                    if (!local)
+                        hipLaunchKernelGGL((k_ps_loop_multi<T, TL, V, STEP_U, REF, false>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                           ctx->stream, lv, ntime, ncol, (const T *)era_T, (const T *)era_QV, (const TL *)ta_pgw,
+                                           (const TL *)evap, (const T *)PS, (const T *)FIS, z, phi_era, dphi, delta_ps, adj_ps, dps_hist,
+                                           p_ref, adj_factor, first ? 1 : 0, np, ctx->d_status, mst, loc);
+                    else if constexpr (V == 1)                                 // MULTI_MAXV = 1: always this branch
+                        hipLaunchKernelGGL((k_ps_loop_multi<T, TL, 1, STEP_U, REF, true>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0,
+                                           ctx->stream, lv, ntime, ncol, (const T *)era_T, (const T *)era_QV, (const TL *)ta_pgw,
+                                           (const TL *)evap, (const T *)PS, (const T *)FIS, z, phi_era, dphi, delta_ps, adj_ps, dps_hist,
+                                           0.0, adj_factor, first ? 1 : 0, np, ctx->d_status, mst, loc);
                 });
             }
             HIPCHK(ctx, hipGetLastError());

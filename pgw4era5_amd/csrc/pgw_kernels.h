@@ -1688,7 +1688,15 @@ constexpr int MULTI_MAX_PASS = 8;
 #ifndef MULTI_MINW
 #define MULTI_MINW 4      // 128 VGPRs (12 bytes of scratch per lane): 1.28 -> 1.21 ms against 3 waves / 136 VGPRs; 5 waves spill 132 bytes and lose
 #endif
-template <typename T, typename TL, int V, int U, bool REF>
+// LOCAL: settings.p_ref_inp = None (step_03:219-253) - the reference level is chosen per column and pass (the first delta
+// level, in file order, that lies above 0.95 of the lowest half-level pressure of both states, functions.py:583-598; never
+// lower than in the pass before, :598), phi_ref of the ERA state is taken at that level (:280-287: recomputed here only
+// when the level changed, it depends on nothing else) and g * dzg at it (:292-295).  `zg` then holds the full
+// (nplev, ncol) records, `pt.p` the plev coordinate in file order, `p_ref_col` / `p_idx_col` the per-column memory that a
+// continuation launch resumes from.  One column per lane (V = 1).
+struct LocalPRef { PlevTable pt; double akN, bkN; double *p_ref_col; int *p_idx_col; };
+
+template <typename T, typename TL, int V, int U, bool REF, bool LOCAL>
 __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, int ntime, long long ncol,
                                                          const T *__restrict__ Tera, const T *__restrict__ QVera,
                                                          const TL *__restrict__ ta, const TL *__restrict__ evap,
@@ -1699,7 +1707,8 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
                                                          double *__restrict__ dps_hist /* [npass][ntime*ncol] */,
                                                          double p_ref_s, double adj_factor, int first, int npass,
                                                          DevStatus *st0 /* errors of the ERA-state scan */,
-                                                         DevStatus *st /* [npass] */) {
+                                                         DevStatus *st /* [npass] */, LocalPRef loc) {
+    static_assert(!LOCAL || V == 1, "local p_ref: one column per lane");
     __shared__ unsigned long long s_max[MULTI_MAX_PASS];          // per pass: max |err| as ordered bits, #valid, levels read
     __shared__ unsigned int s_valid[MULTI_MAX_PASS];
     __shared__ unsigned long long s_touched[MULTI_MAX_PASS];
@@ -1715,26 +1724,31 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
         long long c2 = ix.t * ncol + ix.c;
         const long long lbase = ix.t * N * ncol + ix.c;
         double ps0[V], z[V], dps[V], adj[V], pref[V], tlow[V], phi_ref[V], phi_era[V], dphi[V];
+        int idx = -2;                                              // LOCAL: index of the column's current level (-2: none yet)
         loadv<T, V>(PS + c2, ps0);
         loadv<T, V>(FIS + c2, z);
 #pragma unroll
         for (int v = 0; v < V; ++v) pref[v] = p_ref_s;
         if (first) {
-            int touched0 = 0;
-            scan_columns<T, V, U, true, REF>(lv, lt, ncol, Tera + lbase, QVera + lbase, ps0, z, pref, 0, st0, c2, phi_era, tlow, touched0);
+            if (!LOCAL) {
+                int touched0 = 0;
+                scan_columns<T, V, U, true, REF>(lv, lt, ncol, Tera + lbase, QVera + lbase, ps0, z, pref, 0, st0, c2, phi_era, tlow, touched0);
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                if (REF && !zg.a) dphi[v] = (double)((float)zg.b[c2 + v] * (float)CON_G);      // see k_dphi_clim
-                else dphi[v] = zg.template get<REF>(c2 + v) * CON_G;                             // step_03:292-295
-                dps[v] = 0.0; adj[v] = 0.0;                                                      // :182-184
+                for (int v = 0; v < V; ++v) {
+                    if (REF && !zg.a) dphi[v] = (double)((float)zg.b[c2 + v] * (float)CON_G);      // see k_dphi_clim
+                    else dphi[v] = zg.template get<REF>(c2 + v) * CON_G;                             // step_03:292-295
+                }
+                storev<double, V>(phi_ref_era + c2, phi_era);
+                storev<double, V>(dphi_clim + c2, dphi);
             }
-            storev<double, V>(phi_ref_era + c2, phi_era);
-            storev<double, V>(dphi_clim + c2, dphi);
+#pragma unroll
+            for (int v = 0; v < V; ++v) { dps[v] = 0.0; adj[v] = 0.0; }                              // :182-184
         } else {
             loadv<double, V>(phi_ref_era + c2, phi_era);
             loadv<double, V>(dphi_clim + c2, dphi);
             loadv<double, V>(delta_ps + c2, dps);
             loadv<double, V>(adj_ps + c2, adj);
+            if (LOCAL) { pref[0] = loc.p_ref_col[c2]; idx = loc.p_idx_col[c2]; }
         }
         for (int k = 0; k < npass; ++k) {
             double ps[V];
@@ -1744,6 +1758,28 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
                 ps[v] = ps_of<REF>(ps0[v], dps[v]);                       // :193
             }
             storev<double, V>(dps_hist + (long long)k * n2 + c2, dps);
+            if (LOCAL) {
+                const double p_min_era = (loc.akN + ps0[0] * loc.bkN) * 0.95;                  // :227-228
+                const double p_min_pgw = (loc.akN + ps[0] * loc.bkN) * 0.95;                   // :229-230
+                double p = __builtin_nan("");
+                int j = -1;
+                for (int i = 0; i < loc.pt.n; ++i)
+                    if ((p_min_era > loc.pt.p[i]) && (p_min_pgw > loc.pt.p[i])) { p = loc.pt.p[i]; j = i; break; }   // functions.py:593-596
+                if (j >= 0 && idx >= 0 && pref[0] < p) { p = pref[0]; j = idx; }               // min(p, p_ref_last)  :598
+                if (j < 0) { report(st + k, 19, c2); p = __builtin_nan(""); }                   // step_03:245-251
+                if (j != idx) {                                                                 // (first pass: idx == -2)
+                    pref[0] = p;
+                    idx = j;
+                    if (j >= 0) {
+                        int touched0 = 0;
+                        scan_columns<T, V, U, true, REF>(lv, lt, ncol, Tera + lbase, QVera + lbase, ps0, z, pref, 0, st + k, c2, phi_era,
+                                                         tlow, touched0);                       // :280-287
+                        dphi[0] = zg.template get<REF>((ix.t * loc.pt.n + j) * ncol + ix.c) * CON_G;          // :292-295
+                    } else {
+                        phi_era[0] = p; dphi[0] = p;
+                    }
+                }
+            }
             int touched = 0;
             scan_columns<TL, V, U, false, REF>(lv, lt, ncol, ta + lbase, evap + lbase, ps, z, pref, 0, st + k, c2, phi_ref, tlow,
                                                touched);
@@ -1766,6 +1802,10 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
         }
         storev<double, V>(delta_ps + c2, dps);            // state after the last pass: a continuation launch resumes here
         storev<double, V>(adj_ps + c2, adj);
+        if (LOCAL) {
+            loc.p_ref_col[c2] = pref[0]; loc.p_idx_col[c2] = idx;
+            phi_ref_era[c2] = phi_era[0]; dphi_clim[c2] = dphi[0];
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < npass) {

@@ -653,6 +653,22 @@ def test_local_p_ref_mode_vs_oracle(dtype):
     np.testing.assert_allclose(got['PS'], want['ps_pgw'], rtol=tol)
     np.testing.assert_allclose(got['QV'], want['hus_pgw'], rtol=tol if dtype == np.float64 else 3e-6, atol=1e-18)
     np.testing.assert_allclose(got['max_err'], want['max_err'], rtol=1e-6 if dtype == np.float64 else 1e-5, atol=1e-7)
+    # one launch per pass (k_local_p_ref + two scans, the first form) against the multi-pass kernel's LOCAL variant, and first
+    # launches shorter than the file needs (continuation launches resume the per-column level memory): the same bits
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    for opts in (dict(multipass=0), dict(loop_guess=1), dict(loop_guess=3)):
+        old = {k: ctx.set_option(k, v) for k, v in opts.items()}
+        try:
+            alt = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True, p_ref='local',
+                                         ref_dtype=False)
+        finally:
+            for k, v in old.items():
+                if k != 'loop_guess':
+                    ctx.set_option(k, v)
+        assert alt['n_iter'] == got['n_iter'] and alt['max_err'] == got['max_err'], opts
+        for k in ('PS', 'QV', 'T'):
+            np.testing.assert_array_equal(alt[k], got[k], err_msg=str(opts) + k)
     if dtype == np.float32:
         # reference-dtype mode with the local reference level (float32 delta_ps / ps_pgw / phi): same pass count here,
         # PS within the float32 noise floor of the fast mode
