@@ -94,8 +94,8 @@ int pgw_get_option(pgw_ctx *ctx, int option, int *value);
  * `fn(vals, n, user)`, which must replace every element by its MAXIMUM over the ranks holding the file's other bands
  * (an 8..200-byte all-reduce per loop launch: RCCL / gloo in the caller, see pgw4era5_amd/parallel.py) and return 0.
  * Every rank then takes the same stopping decision, and an error status of one band is returned by all.  n is the same
- * on all ranks at every call.  fn = NULL removes the hook.  Needs the multi-pass loop (PGW_OPT_MULTIPASS = 1, fixed
- * p_ref, PGW_OPT_FULL_COLUMN = 0). */
+ * on all ranks at every call.  fn = NULL removes the hook.  Needs the multi-pass loop (PGW_OPT_MULTIPASS = 1,
+ * PGW_OPT_FULL_COLUMN = 0; fixed or local p_ref). */
 typedef int (*pgw_reduce_max_fn)(double *vals, int n, void *user);
 int pgw_set_reduce_hook(pgw_ctx *ctx, pgw_reduce_max_fn fn, void *user);
 const char *pgw_last_error(pgw_ctx *ctx);

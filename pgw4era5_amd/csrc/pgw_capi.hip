@@ -886,8 +886,8 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     const bool local = local_nplev > 0;
     // several passes per launch: fixed p_ref, wave-level early exit (the full-column option is a per-pass traffic probe)
     const bool multipass = ctx->opt[PGW_OPT_MULTIPASS] && !full_column;
-    NEED(ctx, !ctx->reduce_fn || (multipass && !local), "a reduce hook (latitude-band sharding) needs the multi-pass loop: fixed p_ref, "
-                                                         "PGW_OPT_MULTIPASS = 1, PGW_OPT_FULL_COLUMN = 0");
+    NEED(ctx, !ctx->reduce_fn || multipass, "a reduce hook (latitude-band sharding) needs the multi-pass loop: "
+                                            "PGW_OPT_MULTIPASS = 1, PGW_OPT_FULL_COLUMN = 0");
     PlevTable ptf;
     memset(&ptf, 0, sizeof(ptf));
     if (local) {
@@ -1109,9 +1109,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
          a->pshist_b, "delta record pointer is NULL");
     NEED(ctx, a->PS_out && a->T_out && a->QV_out && a->U_out && a->V_out, "output pointer is NULL");
     NEED(ctx, a->max_n_iter >= 1 && a->max_n_iter <= 1000, "bad max_n_iter");
-    NEED(ctx, !ctx->reduce_fn || (!a->local_p_ref && ctx->opt[PGW_OPT_MULTIPASS] && !ctx->opt[PGW_OPT_FULL_COLUMN]),
-         "a reduce hook (latitude-band sharding) needs the multi-pass loop: fixed p_ref, PGW_OPT_MULTIPASS = 1, "
-         "PGW_OPT_FULL_COLUMN = 0");
+    NEED(ctx, !ctx->reduce_fn || (ctx->opt[PGW_OPT_MULTIPASS] && !ctx->opt[PGW_OPT_FULL_COLUMN]),
+         "a reduce hook (latitude-band sharding) needs the multi-pass loop: PGW_OPT_MULTIPASS = 1, PGW_OPT_FULL_COLUMN = 0");
     const bool exact = (a->x_hi == 0.0);
     const bool ref = a->ref_dtype != 0;
     NEED(ctx, !ref || dtype == PGW_F32, "ref_dtype = 1 is the float32-file mode: dtype must be PGW_F32");

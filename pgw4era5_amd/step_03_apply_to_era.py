@@ -349,8 +349,8 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     ctx = default_context()
     if band is not None:
         from .parallel import band_rows
-        if i_reinterp or p_ref == 'local':
-            raise ValueError('latitude-band sharding of one file needs the fixed-p_ref loop (i_reinterp = 0, p_ref_inp set)')
+        if i_reinterp:
+            raise ValueError('latitude-band sharding of one file needs the multi-pass loop (settings.i_reinterp = 0)')
         if reduce_max is None and band[1] > 1:
             raise ValueError('band sharding over more than one rank needs reduce_max (parallel.band_max_hook)')
         j0, j1 = band_rows(np.asarray(era['T']).shape[-2], band[0], band[1])

@@ -421,7 +421,8 @@ res = None
 try:
     for rep in range(2):                       # twice: the second file starts from the first one's pass count (loop_guess)
         res = s3.pgw_for_era5_arrays(case['era'], case['deltas'], case['delta_times'], case['plev'], case['target_dt'],
-                                     ignore_top_pressure_error=(sys.argv[3] == 't'), band=(rank, world), reduce_max=band_max_hook())
+                                     ignore_top_pressure_error=(sys.argv[3] == 't'), band=(rank, world), reduce_max=band_max_hook(),
+                                     p_ref=(None if len(sys.argv) < 5 or sys.argv[4] == 'fixed' else 'local'))
     np.savez(os.path.join(out_dir, 'band%%d.npz' %% rank), n_iter=res['n_iter'], max_err=np.asarray(res['max_err']),
              **{k: res[k] for k in ('PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE')})
     msg = 'ok'
@@ -434,28 +435,29 @@ dist.destroy_process_group()
 '''
 
 
-def _run_bands(tmp_path, mode, top='t', port='29541'):
+def _run_bands(tmp_path, mode, top='t', port='29541', p_ref='fixed'):
     script = tmp_path / 'band.py'
     script.write_text(BAND_SCRIPT % ROOT)
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', port, str(script), str(tmp_path), mode, top],
+                        '--master-addr', '127.0.0.1', '--master-port', port, str(script), str(tmp_path), mode, top, p_ref],
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
     assert r.returncode == 0, r.stderr[-3000:]
     return {k: open(str(tmp_path / ('msg%d.txt' % k))).read() for k in (0, 1) if os.path.exists(str(tmp_path / ('msg%d.txt' % k)))}
 
 
-def test_one_file_in_two_latitude_bands_is_bit_identical(tmp_path):
+@pytest.mark.parametrize('p_ref', ['fixed', 'local'])
+def test_one_file_in_two_latitude_bands_is_bit_identical(tmp_path, p_ref):
     """SURVEY.md section 8e, row 2 (latency mode): ONE file split into two latitude bands over two ranks (gloo here, both on
     the one GPU; RCCL on a node), the loop's stopping test made global by an all-reduce MAX of the per-pass maxima
     (pgw_set_reduce_hook).  The bands put together must be the single-process result bit for bit - same pass count, same
     max|err| history (step_03_apply_to_era.py:189, 308: the maximum is over all columns)."""
     from pgw4era5_amd import synthetic, step_03_apply_to_era as s3
     from pgw4era5_amd.parallel import band_rows
-    msgs = _run_bands(tmp_path, 'clean')
+    msgs = _run_bands(tmp_path, 'clean', port='29541' if p_ref == 'fixed' else '29547', p_ref=p_ref)
     assert msgs == {0: 'ok', 1: 'ok'}
     case = synthetic.make_case(nlat=21, nlon=32, nlev=40, seed=11, dtype=np.float64)
     whole = s3.pgw_for_era5_arrays(case['era'], case['deltas'], case['delta_times'], case['plev'], case['target_dt'],
-                                   ignore_top_pressure_error=True)
+                                   ignore_top_pressure_error=True, p_ref=(None if p_ref == 'fixed' else 'local'))
     bands = [np.load(str(tmp_path / ('band%d.npz' % r))) for r in range(2)]
     assert band_rows(21, 0, 2) == (0, 11) and band_rows(21, 1, 2) == (11, 21)
     for b in bands:
