@@ -751,8 +751,33 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
         double xprev = -__builtin_inf();
         int ci = -2;                 // cached bracket index: values y[ci], y[ci+1]
         double y_lo = 0.0, y_hi = 0.0;
-        for (int l = 0; l < N; ++l) {
-            double p = ptg ? (double)ptg[(long long)l * ncol] : (lt.akm[l] + psv * lt.bkm[l]);
+        // chunks of 4 target levels: the next chunk's target pressures and addends are in flight while this one is
+        // interpolated (one memory latency per chunk instead of per level; each element is touched once: streaming forms)
+        constexpr int U = 4;
+        double np_[U], na_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long o = (long long)(u < N ? u : N - 1) * ncol;
+            np_[u] = ptg ? (double)SIG_LD(ptg + o) : 0.0;
+            na_[u] = add_to ? (double)SIG_LD(add_to + obase + o) : 0.0;
+        }
+        for (int l0 = 0; l0 < N; l0 += U) {
+        double cp_[U], ca_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { cp_[u] = np_[u]; ca_[u] = na_[u]; }
+        if (l0 + U < N) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long o = (long long)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * ncol;
+                if (ptg) np_[u] = (double)SIG_LD(ptg + o);
+                if (add_to) na_[u] = (double)SIG_LD(add_to + obase + o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int l = l0 + u;
+            if (l >= N) break;
+            double p = ptg ? cp_[u] : (lt.akm[l] + psv * lt.bkm[l]);
             if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
             double x = pgw_log_tab(p, lt.logtab);
             if (!(x >= xprev)) j = 0;
@@ -774,9 +799,10 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
                     y = y_lo + (x - x1) * (y_hi - y_lo) / (xs - x1);    // :575-578
                 }
             }
-            if (add_to) y = (double)add_to[obase + (long long)l * ncol] + y;   // step_03:170-173
-            out[obase + (long long)l * ncol] = (T)y;
+            if (add_to) y = ca_[u] + y;                                        // step_03:170-173
+            SIG_ST((T)y, out + obase + (long long)l * ncol);
             xprev = (x == x) ? x : __builtin_inf();
+        }
         }
     }
     if (check_top) {
