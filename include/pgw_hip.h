@@ -201,6 +201,16 @@ int pgw_vert_interp_delta(pgw_ctx *ctx, int dtype, int ntime, int nplev, int nle
                           const void *targ_P, const void *ps,
                           int ignore_top, const void *add_to, void *out);
 
+/* f3  settings.i_reinterp = 1, one variable of one loop pass (step_03_apply_to_era.py:202-216; ua / va after the loop,
+ * :330-343):  out = interp_logp_4d(era_field, pa_era, pa_pgw, extrapolate='constant') + load_delta_interp(var, pa_pgw)
+ * as ONE kernel: pa_era = akm + ps_era*bkm (source axis of the first term) and pa_pgw = akm + ps_pgw*bkm (target of
+ * both) are rebuilt in registers from the two surface-pressure fields (ntime, ncol) and pgw_set_levels, the delta
+ * arguments are those of pgw_vert_interp_delta.  era_field, out: (ntime, nlev, ncol). */
+int pgw_reinterp_field(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol, const double *plev,
+                       const void *delta_b, const void *delta_a, double x_hi, double x_new, const void *dsfc_b,
+                       const void *dsfc_a, const void *pshist_b, const void *pshist_a, const void *era_field,
+                       const void *ps_era, const void *ps_pgw, int ignore_top, void *out);
+
 /* replace_delta_sfc(source_P, ps_hist, delta, delta_sfc)  functions.py:343-366, on many columns:
  * plev_asc (nplev, host, ascending); delta (ntime, nplev, ncol) in ascending order;
  * delta_sfc, ps_hist (ntime, ncol); outputs out_P, out_delta (ntime, nplev, ncol). */

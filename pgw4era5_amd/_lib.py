@@ -78,6 +78,7 @@ SIGNATURES = {
     'pgw_time_lerp': (_i, [_vp, _i, _ll, _vp, _vp, _d, _d, _vp]),
     'pgw_vert_interp_delta': (_i, [_vp, _i, _i, _i, _i, _ll, _dp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i, _vp, _vp]),
+    'pgw_reinterp_field': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'pgw_replace_delta_sfc': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _vp, _vp, _vp]),
     'pgw_integrate_tos': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp]),
     'pgw_adjust_ps_step': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _i, _dp]),

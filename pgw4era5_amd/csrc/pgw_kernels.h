@@ -825,6 +825,149 @@ __global__ __launch_bounds__(BLOCK) void k_vert_interp_delta(PlevTable pt, Level
     }
 }
 
+// settings.i_reinterp = 1 (step_03_apply_to_era.py:202-216, 330-343), one variable, one pass, one kernel:
+//   out = interp_logp_4d(era_field, pa_era, pa_pgw, 'constant')  +  load_delta_interp(var, pa_pgw)
+// with both hybrid pressure fields rebuilt in registers from the two surface pressures (pa_era = akm + ps_era bkm is the
+// SOURCE axis of the first term, pa_pgw = akm + ps_pgw bkm the TARGET of both), so neither 4-D pressure array nor the
+// re-interpolated ERA field is materialised: reads the ERA field once, writes the result once (composed from the
+// function-level entries the same work is two launches and five 4-D passes).  The ERA column is followed with a
+// three-value window (level j-1, j and the raw value of j+1 in flight): the two pressure sets differ by the loop's
+// surface-pressure increment, so the bracket of target level l lies next to source level l.  Selection rule and lerp
+// arithmetic are interp_extrap_1d's (functions.py:527-578, 'constant'); all logarithms from pgw_log_tab.
+template <typename T, bool HAS_SFC>
+__global__ __launch_bounds__(BLOCK) void k_reinterp_field(PlevTable pt, Levels lv, int ntime, long long ncol,
+                                                          DeltaSrc<T> dsrc, DeltaSrc<T> sfc, DeltaSrc<T> psh,
+                                                          const T *__restrict__ era_field, const T *__restrict__ ps_era,
+                                                          const T *__restrict__ ps_pgw, int check_top,
+                                                          T *__restrict__ out, DevStatus *st) {
+    __shared__ double s_mint[BLOCK / 64], s_mins[BLOCK / 64];
+    __shared__ int s_nan[BLOCK / 64];
+    __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
+    const int S = pt.n, N = lv.nlev;
+    if (threadIdx.x < MAX_PLEV) {
+        s_p[threadIdx.x] = pt.p[threadIdx.x];
+        s_lnp[threadIdx.x] = pt.lnp[threadIdx.x];
+    }
+    __syncthreads();
+    long long flat = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double min_t = __builtin_inf(), min_s = __builtin_inf();
+    int nanflag = 0;
+    if (flat < (long long)ntime * ncol) {
+        long long t = flat / ncol, c = flat - t * ncol;
+        long long c2 = flat;
+        long long dbase = t * S * ncol + c;      // delta records are (ntime, S, ncol), file order
+        int ksfc = -1;                           // level moved to ps_hist
+        bool fill_below = false;
+        double d_sfc = 0.0, lnps = 0.0, pshv = 0.0;
+        bool bad = false;
+        if (HAS_SFC) {
+            pshv = psh.get(c2);
+            d_sfc = sfc.get(c2);
+            if (pshv > pt.pmax) {                                  // functions.py:356-359
+                ksfc = S - 1;
+            } else if (pshv < pt.pmin) {                           // :360-361
+                bad = true;
+            } else {                                               // :362-365
+                for (int i = 0; i < S; ++i) if (pshv > s_p[i]) ksfc = i;
+                if (ksfc < 0) bad = true;
+                fill_below = true;
+            }
+            if (bad) { report(st, 15, flat); ksfc = -1; }
+            lnps = pgw_log_tab(pshv, lt.logtab);
+        }
+        auto srcx = [&](int i) -> double { return (HAS_SFC && i == ksfc) ? lnps : s_lnp[i]; };
+        auto srcy = [&](int i) -> double {
+            if (HAS_SFC && ksfc >= 0 && (i == ksfc || (fill_below && i > ksfc))) return d_sfc;
+            return dsrc.get(dbase + (long long)(S - 1 - i) * ncol);
+        };
+        if (check_top) {
+            for (int i = 0; i < S; ++i) {                          // np.min(source_P) over this column (:417)
+                double p = (HAS_SFC && i == ksfc) ? pshv : s_p[i];
+                if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
+            }
+        }
+        const double pse = (double)ps_era[c2], psv = (double)ps_pgw[c2];
+        const long long obase = t * (long long)N * ncol + c;
+        const T *pf = era_field + obase;
+        // ---- window over the ERA column: (wxm, wym) level wj - 1, (wxj, wyj) level wj, and the raw values of levels
+        // wj + 1 .. wj + 4 in flight (q0..q3: the window moves one level per target level, four loads stay outstanding)
+        int wj;
+        double wxm = 0, wym = 0, wxj, wyj, q0, q1, q2, q3;
+        auto wload = [&](int lev) -> double { return (double)SIG_LD(pf + (long long)(lev < N ? lev : N - 1) * ncol); };
+        auto wreset = [&]() {
+            wj = 0;
+            wxj = pgw_log_tab(lt.akm[0] + pse * lt.bkm[0], lt.logtab);
+            wyj = wload(0);
+            q0 = wload(1); q1 = wload(2); q2 = wload(3); q3 = wload(4);
+        };
+        wreset();
+        int j = 0;
+        double xprev = -__builtin_inf();
+        int ci = -2;                 // cached bracket index of the delta: values y[ci], y[ci+1]
+        double y_lo = 0.0, y_hi = 0.0;
+        for (int l = 0; l < N; ++l) {
+            const double p = lt.akm[l] + psv * lt.bkm[l];                                   // step_03:196-197
+            if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
+            const double x = pgw_log_tab(p, lt.logtab);
+            if (__builtin_expect(!(x >= xprev), 0)) { j = 0; wreset(); }                    // descending / NaN target: both scans restart
+            // -- the ERA field at this pressure (interp_extrap_1d, 'constant')
+            while (wj < N && !(wxj == x || wxj > x)) {
+                wxm = wxj; wym = wyj;
+                ++wj;
+                if (wj < N) {
+                    wxj = pgw_log_tab(lt.akm[wj] + pse * lt.bkm[wj], lt.logtab);
+                    wyj = q0; q0 = q1; q1 = q2; q2 = q3;
+                    q3 = wload(wj + 4);
+                }
+            }
+            double e;
+            if (wj >= N) e = wym;                                   // beyond the last source level: its value   :558-560
+            else if (wxj == x || wj == 0) e = wyj;                  // exact :540-543 / before the first: its value :534-536
+            else e = wym + (x - wxm) * (wyj - wym) / (wxj - wxm);   // :575-578
+            // -- the climate delta at this pressure (as k_vert_interp_delta)
+            while (j < S) {
+                double xs = srcx(j);
+                if (xs == x || xs > x) break;
+                ++j;
+            }
+            double y;
+            if (j >= S) {
+                y = srcy(S - 1);
+            } else {
+                double xs = srcx(j);
+                if (xs == x) y = srcy(j);
+                else if (j == 0) y = srcy(0);
+                else {
+                    if (ci != j - 1) { y_lo = srcy(j - 1); y_hi = srcy(j); ci = j - 1; }
+                    double x1 = srcx(j - 1);
+                    y = y_lo + (x - x1) * (y_hi - y_lo) / (xs - x1);
+                }
+            }
+            SIG_ST((T)(e + y), out + obase + (long long)l * ncol);                          // vars_era + deltas  :216
+            xprev = (x == x) ? x : __builtin_inf();
+        }
+    }
+    if (check_top) {
+        double wt = wave_min(min_t), ws = wave_min(min_s);
+        int wn = nanflag;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wn |= __shfl_xor(wn, off, 64);
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_mint[w] = wt; s_mins[w] = ws; s_nan[w] = wn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mt = s_mint[0], ms = s_mins[0];
+            int nn = s_nan[0];
+            for (int i = 1; i < BLOCK / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
+            if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
+            if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
+            if (nn) atomicOr(&st->nan_seen, nn);
+        }
+    }
+}
+
 // =====================================================================================
 // Fused per-file delta kernels (production path of pgw_step03_file).
 //

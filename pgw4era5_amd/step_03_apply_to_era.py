@@ -264,9 +264,7 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     kref = np.nonzero(plev == p_ref)[0]
     if len(kref) != 1:
         raise KeyError(p_ref)
-    # ERA state: pa_era (4-D, needed as source axis), RELHUM (step_03:87-94), phi_ref_era, g*dzg
-    pa_era = buf('_pa_era', T.shape)
-    ctx._check(lib.pgw_pressure_levels(h, tag, nt, ncol, PS.ptr, None, pa_era.ptr))
+    # ERA state: RELHUM (step_03:87-94), phi_ref_era, g*dzg (the 4-D pressure fields live in registers, k_reinterp_field)
     relhum = buf('_RELHUM', T.shape)
     ctx._check(lib.pgw_specific_to_relative_humidity_hybrid(h, tag, nt, ncol, QV.ptr, PS.ptr, T.ptr, relhum.ptr))
     phi_era = buf('_phi_era', PS.shape, f64)
@@ -279,20 +277,18 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
         ctx._check(lib.pgw_time_lerp(h, tag, zb.size, zb.ptr, za.ptr, x_hi, x_new, dzg.ptr))
     dphi = ctx.to_device(dzg.numpy().astype(np.float64) * CON_G, f64)          # step_03:292-293 (2-D, once)
     delta_ps, adj_ps = ctx.zeros(PS.shape, f64), ctx.zeros(PS.shape, f64)        # :182-184
-    ps_pgw, pa_pgw = buf('PS', PS.shape), buf('_pa_pgw', T.shape)
-    tmp = buf('_tmp', T.shape)
+    ps_pgw = buf('PS', PS.shape)
 
     def reinterp(var, era_field, target):
-        """interp_logp_4d(era, pa_era, pa_pgw, 'constant') + load_delta_interp(var, pa_pgw)  :209-216"""
-        ctx._check(lib.pgw_interp_logp_4d(h, tag, nt, N, N, ncol, era_field.ptr, pa_era.ptr, pa_pgw.ptr, 2, 0, tmp.ptr))
+        """interp_logp_4d(era, pa_era, pa_pgw, 'constant') + load_delta_interp(var, pa_pgw)  :209-216, one kernel"""
         if var in ('ta', 'hur'):
             sfc, psh = dev[var + 's'], dev['ps_hist']
             sb, sa, pb, pa_ = sfc.slab(rb).ptr, sfc.slab(ra).ptr, psh.slab(rb).ptr, psh.slab(ra).ptr
         else:
             sb = sa = pb = pa_ = None
-        ctx._check(lib.pgw_vert_interp_delta(h, tag, nt, len(plev), N, ncol, plev.ctypes.data_as(_dp),
-                                             dev[var].slab(rb).ptr, dev[var].slab(ra).ptr, x_hi, x_new, sb, sa, pb, pa_,
-                                             pa_pgw.ptr, None, 1 if ignore_top_pressure_error else 0, tmp.ptr, target.ptr))
+        ctx._check(lib.pgw_reinterp_field(h, tag, nt, len(plev), ncol, plev.ctypes.data_as(_dp),
+                                          dev[var].slab(rb).ptr, dev[var].slab(ra).ptr, x_hi, x_new, sb, sa, pb, pa_,
+                                          era_field.ptr, PS.ptr, ps_pgw.ptr, 1 if ignore_top_pressure_error else 0, target.ptr))
 
     ta_pgw, hur_pgw = buf('T', T.shape), buf('_hur_pgw', T.shape)
     err = np.inf
@@ -301,7 +297,6 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     max_err = C.c_double()
     while err > S.thresh_phi_ref_max_error:                                       # :189
         ctx._check(lib.pgw_update_ps(h, tag, n2, PS.ptr, delta_ps.ptr, adj_ps.ptr, ps_pgw.ptr))   # :192-193
-        ctx._check(lib.pgw_pressure_levels(h, tag, nt, ncol, ps_pgw.ptr, None, pa_pgw.ptr))        # :196-197
         reinterp('ta', T, ta_pgw)
         reinterp('hur', relhum, hur_pgw)
         ctx._check(lib.pgw_adjust_ps_step(h, tag, nt, ncol, ta_pgw.ptr, hur_pgw.ptr, PS.ptr, FIS.ptr, phi_era.ptr,
