@@ -715,6 +715,60 @@ def test_reinterp_mode_vs_oracle(dtype):
     assert np.abs(base['T'] - got['T']).max() > 1e-6
 
 
+@pytest.mark.parametrize('with_sfc', [True, False])
+def test_reinterp_field_kernel_vs_oracle_composition(with_sfc):
+    """pgw_reinterp_field alone: interp_logp_4d(era, pa_era, pa_pgw, 'constant') + vert_interp_delta(delta, pa_pgw) of the
+    oracle, with surface pressures far apart (+-8 %: the re-interpolation extrapolates at both ends of the column and the
+    window over the ERA column moves by several levels), an exact record and a time-interpolated one."""
+    import ctypes as C
+    from pgw4era5_amd.device import default_context, dtype_tag
+    ctx = default_context()
+    c = _case(7, 9, 23, seed=33)
+    era, d = c['era'], c['deltas']
+    ctx.set_levels(era['ak'], era['bk'])
+    rng = np.random.default_rng(5)
+    ps_era = era['PS']
+    ps_pgw = ps_era * (1 + 0.08 * (2 * rng.random(ps_era.shape) - 1))
+    akm, bkm = O.full_level_coeffs(era['ak'], era['bk'])
+    _, pa_era = O.hybrid_pressure(era['ak'], era['bk'], ps_era, akm, bkm)
+    _, pa_pgw = O.hybrid_pressure(era['ak'], era['bk'], ps_pgw, akm, bkm)
+    nt, N, nlat, nlon = era['T'].shape
+    ncol = nlat * nlon
+    plev = np.ascontiguousarray(c['plev'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    for rb, ra, x_hi, x_new in ((3, 3, 0.0, 0.0), (3, 4, 31.0, 11.5)):
+        if x_hi == 0.0:
+            delta, dsfc, psh = d['ta'][rb:rb + 1], d['tas'][rb:rb + 1], d['ps_hist'][rb:rb + 1]
+        else:
+            lerp = lambda v: (v[ra:ra + 1] - v[rb:rb + 1]) / x_hi * x_new + v[rb:rb + 1]
+            delta, dsfc, psh = lerp(d['ta']), lerp(d['tas']), lerp(d['ps_hist'])
+        want = O.interp_logp_4d(era['T'], pa_era, pa_pgw, extrapolate='constant') + \
+            O.vert_interp_delta(delta, c['plev'], pa_pgw, dsfc if with_sfc else None, psh if with_sfc else None,
+                                ignore_top_pressure_error=True)
+        dev = {k: ctx.to_device(np.ascontiguousarray(v)) for k, v in
+               dict(f=era['T'], pe=ps_era, pp=ps_pgw, db=d['ta'][rb], da=d['ta'][ra], sb=d['tas'][rb], sa=d['tas'][ra],
+                    hb=d['ps_hist'][rb], ha=d['ps_hist'][ra]).items()}
+        out = ctx.empty(era['T'].shape, np.float64)
+        sfc = (dev['sb'].ptr, dev['sa'].ptr, dev['hb'].ptr, dev['ha'].ptr) if with_sfc else (None, None, None, None)
+        ctx._check(ctx.lib.pgw_reinterp_field(ctx.handle, dtype_tag(np.dtype('float64')), nt, len(plev), ncol, plev.ctypes.data_as(dp),
+                                              dev['db'].ptr, dev['da'].ptr, x_hi, x_new, *sfc, dev['f'].ptr, dev['pe'].ptr,
+                                              dev['pp'].ptr, 1, out.ptr))
+        np.testing.assert_allclose(out.numpy(), want, rtol=1e-10, atol=1e-12)
+    # identical surface pressures: the re-interpolated ERA field is the field itself (exact hits, functions.py:540-543)
+    ctx._check(ctx.lib.pgw_reinterp_field(ctx.handle, dtype_tag(np.dtype('float64')), nt, len(plev), ncol, plev.ctypes.data_as(dp),
+                                          dev['db'].ptr, dev['da'].ptr, 0.0, 0.0, *sfc, dev['f'].ptr, dev['pe'].ptr, dev['pe'].ptr,
+                                          1, out.ptr))
+    same = O.vert_interp_delta(d['ta'][rb:rb + 1], c['plev'], pa_era, d['tas'][rb:rb + 1] if with_sfc else None,
+                               d['ps_hist'][rb:rb + 1] if with_sfc else None, ignore_top_pressure_error=True)
+    np.testing.assert_allclose(out.numpy() - era['T'], same, rtol=0, atol=1e-10)
+    # the model-top check is the one of vert_interp_delta (functions.py:417-425)
+    with pytest.raises(ValueError) as e:
+        ctx._check(ctx.lib.pgw_reinterp_field(ctx.handle, dtype_tag(np.dtype('float64')), nt, len(plev), ncol, plev.ctypes.data_as(dp),
+                                              dev['db'].ptr, dev['da'].ptr, 0.0, 0.0, *sfc, dev['f'].ptr, dev['pe'].ptr,
+                                              dev['pp'].ptr, 0, out.ptr))
+    assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
+
+
 def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
     """it > max_n_iter raises even if that pass converged (step_03:313-319)."""
     from pgw4era5_amd import step_03_apply_to_era as s3
