@@ -24,7 +24,8 @@ kernel, HIP-event timed inside this run, beside the figure recomputed from the c
 summary), `cpu_baseline` (the numpy oracle on the host cores, rank 0, N = 1 only: one process and
 file-parallel processes, on bounded latitude bands of the same file) and, at N = 1, `extras`
 (PCIe-inclusive rate, end-to-end rate through the command line incl. NetCDF I/O, step_02 regridding of
-BASELINE.json configs[3], float32-storage rates) - reported, never `value`.
+BASELINE.json configs[3], float32-storage rates) - reported, never `value`; at N > 1 also `latency_mode`: ONE file over
+all ranks in latitude bands, the loop's stopping test made global by an all-reduce MAX (RCCL) of the per-pass maxima.
 """
 import argparse
 import datetime as dt
