@@ -146,6 +146,13 @@ int pgw_specific_to_relative_humidity(pgw_ctx *ctx, int dtype, long long n,
                                       const void *hus, const void *pa, const void *ta, void *hur);
 int pgw_relative_to_specific_humidity(pgw_ctx *ctx, int dtype, long long n,
                                       const void *hur, const void *pa, const void *ta, void *hus);
+/* the leaf helpers of the same block, for callers that use them directly (flat, n elements; b is ignored by 2..4):
+ *   which = 0  specific_humidity_to_vapor_pressure(hus = a, pa = b)             functions.py:58-64
+ *           1  vapor_pressure_to_specific_humidity(vapp = a, pa = b)            :66-72
+ *           2  saturation_vapor_pressure_water_or_ice(pa, ta = a, water=True)   :74-89
+ *           3  ... water=False (over ice)
+ *           4  saturation_vapor_pressure_water_and_ice(pa, ta = a)              :91-105 */
+int pgw_humidity_leaf(pgw_ctx *ctx, int dtype, int which, long long n, const void *a, const void *b, void *out);
 /* same, with pa = akm + ps*bkm rebuilt in registers instead of read (saves the 4-D pa array
  * step_03:87-94 / :196-197,262-266 materialise).  fields (ntime, nlev, ncol), ps (ntime, ncol) */
 int pgw_specific_to_relative_humidity_hybrid(pgw_ctx *ctx, int dtype, int ntime, long long ncol,

@@ -71,6 +71,7 @@ SIGNATURES = {
     'pgw_pressure_levels': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp]),
     'pgw_specific_to_relative_humidity': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp]),
     'pgw_relative_to_specific_humidity': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp]),
+    'pgw_humidity_leaf': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp]),
     'pgw_specific_to_relative_humidity_hybrid': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp]),
     'pgw_relative_to_specific_humidity_hybrid': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp]),
     'pgw_integ_geopot': (_i, [_vp, _i, _i, _i, _ll, _vp, _vp, _vp, _vp, _d, _vp, _vp, _i]),

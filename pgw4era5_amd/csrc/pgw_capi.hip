@@ -508,6 +508,28 @@ extern "C" int pgw_relative_to_specific_humidity(pgw_ctx *ctx, int dtype, long l
     return humidity_flat<1>(ctx, PGW_K_RH_TO_Q, dtype, n, hur, pa, ta, hus);
 }
 
+extern "C" int pgw_humidity_leaf(pgw_ctx *ctx, int dtype, int which, long long n, const void *a, const void *b, void *out) {
+    NEED(ctx, dtype == PGW_F32 || dtype == PGW_F64, "dtype must be PGW_F32 or PGW_F64");
+    NEED(ctx, which >= 0 && which <= 4, "which must be 0..4");
+    NEED(ctx, n >= 1 && a && out && (which >= 2 || b), "bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    unsigned int nb = nblocks(n, BLOCK);
+    if (nb > 256 * 16) nb = 256 * 16;
+#define LEAF(W) hipLaunchKernelGGL((k_humidity_leaf<T, W>), dim3(nb), dim3(BLOCK), 0, ctx->stream, n, (const T *)a, (const T *)b, (T *)out)
+    DISPATCH_T(dtype, {
+        switch (which) {
+            case 0: LEAF(0); break;
+            case 1: LEAF(1); break;
+            case 2: LEAF(2); break;
+            case 3: LEAF(3); break;
+            default: LEAF(4); break;
+        }
+    });
+#undef LEAF
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 template <int MODE>
 static int humidity_hybrid(pgw_ctx *ctx, int kid, int dtype, int ntime, long long ncol, const void *x,
                            const void *ps, const void *ta, void *out) {

@@ -119,6 +119,23 @@ __global__ __launch_bounds__(BLOCK) void k_humidity_flat(long long n, const T *_
     }
 }
 
+// the leaf helpers (functions.py:58-105), literal forms with IEEE divisions
+template <typename T, int WHICH>
+__global__ __launch_bounds__(BLOCK) void k_humidity_leaf(long long n, const T *__restrict__ a, const T *__restrict__ b,
+                                                         T *__restrict__ out) {
+    long long stride = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const double x = (double)a[i];
+        double r;
+        if (WHICH == 0) { const double p = (double)b[i]; r = x * p / (CON_MW_MD + 0.378 * x); }
+        else if (WHICH == 1) { const double p = (double)b[i]; r = CON_MW_MD * x / (p - (1 - CON_MW_MD) * x); }
+        else if (WHICH == 2) r = 611.21 * pgw_exp(17.502 * (x - 273.16) / (x - 32.19));
+        else if (WHICH == 3) r = 611.21 * pgw_exp(22.587 * (x - 273.16) / (x - (-0.7)));
+        else r = esat_mixed(x);
+        out[i] = (T)r;
+    }
+}
+
 // same with pa = akm + ps*bkm rebuilt in registers (no 4-D pressure array)
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_humidity_hybrid(Levels lv, int ntime, long long ncol,

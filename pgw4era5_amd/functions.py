@@ -135,6 +135,47 @@ def relative_to_specific_humidity(hur, pa, ta):
     return _out(ctx, out, hur)
 
 
+def _humidity_leaf(which, a, b, like):
+    ctx = default_context()
+    dt = _common_dtype(a) if b is None else _common_dtype(a, b)
+    shp = _raw(a).shape
+    da = _dev(ctx, a, dt)
+    db = None
+    if b is not None:
+        b = _aligned(b, a)
+        db = _dev(ctx, np.broadcast_to(_raw(b), shp) if not isinstance(_raw(b), DeviceArray) else b, dt)
+    out = ctx.empty(shp, dt)
+    ctx._check(ctx.lib.pgw_humidity_leaf(ctx.handle, dtype_tag(dt), which, out.size, da.ptr, db.ptr if db is not None else None, out.ptr))
+    return _out(ctx, out, like)
+
+
+def specific_humidity_to_vapor_pressure(hus, pa):
+    """e = hus * pa / (0.622 + 0.378 * hus).  reference functions.py:58-64."""
+    return _humidity_leaf(0, hus, pa, hus)
+
+
+def vapor_pressure_to_specific_humidity(vapp, pa):
+    """hus = 0.622 * vapp / (pa - 0.378 * vapp).  reference functions.py:66-72."""
+    return _humidity_leaf(1, vapp, pa, vapp)
+
+
+def saturation_vapor_pressure_water_or_ice(pa, ta, water=True):
+    """IFS (7.93) saturation vapour pressure over water or over ice; `pa` is unused, as in the reference (functions.py:74-89)."""
+    return _humidity_leaf(2 if water else 3, ta, None, ta)
+
+
+def saturation_vapor_pressure_water_and_ice(pa, ta):
+    """IFS (7.92) mixed-phase saturation vapour pressure.  reference functions.py:91-105."""
+    return _humidity_leaf(4, ta, None, ta)
+
+
+def dt64_to_dt(dt64):
+    """numpy datetime64 -> python datetime (UTC).  reference functions.py:38-51."""
+    import datetime as _datetime
+    timestamp = (np.datetime64(dt64, 's') - np.datetime64('1970-01-01T00:00:00')) / np.timedelta64(1, 's')
+    return _datetime.datetime.utcfromtimestamp(float(timestamp))
+
+
 # ------------------------------------------------------------------------------- pressure
 def hybrid_pressure(ak, bk, ps, akm=None, bkm=None):
     """pa_hl = ak + ps*bk, pa = akm + ps*bkm  (reference step_03_apply_to_era.py:64-88,196-199;

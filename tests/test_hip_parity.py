@@ -88,6 +88,14 @@ def test_humidity_golden(F, golden):
     q2 = F.relative_to_specific_humidity(rh, pa, ta)
     ok = pa > 10 * g['hum_e']
     np.testing.assert_allclose(q2[ok], q[ok], rtol=1e-11, atol=1e-18)
+    # the leaf helpers of functions.py:58-105 under their own names, against the reference's values
+    np.testing.assert_array_equal(F.specific_humidity_to_vapor_pressure(q, pa), g['hum_e'])          # arithmetic only: same bits
+    np.testing.assert_array_equal(F.vapor_pressure_to_specific_humidity(g['hum_e'], pa), g['hum_q_from_e'])
+    np.testing.assert_allclose(F.saturation_vapor_pressure_water_or_ice(pa, ta, water=True), g['hum_esat_water'], rtol=1e-14)
+    np.testing.assert_allclose(F.saturation_vapor_pressure_water_or_ice(pa, ta, water=False), g['hum_esat_ice'], rtol=1e-14)
+    np.testing.assert_allclose(F.saturation_vapor_pressure_water_and_ice(pa, ta), es, rtol=1e-14)
+    import datetime as _dt
+    assert F.dt64_to_dt(np.datetime64('2006-08-02T03:00:00')) == _dt.datetime(2006, 8, 2, 3, 0, 0)
 
 
 def test_integrate_tos_golden(F, golden):
