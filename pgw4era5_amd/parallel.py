@@ -138,6 +138,32 @@ def _dist_env():
     return rank, world
 
 
+def starmap_helper(tup):
+    """reference parallel.py:12-15."""
+    tup = dict(tup)
+    func = tup.pop('func')
+    return func(**tup)
+
+
+def run_starmap(func, fargs={}, njobs=1, run_async=False):
+    """`run_starmap(func, fargs, njobs, run_async)` of the reference (parallel.py:18-32): `fargs` is the list IterMP.run builds -
+    one kwargs dict per task (wrapped in a 1-tuple with the function under 'func' when njobs > 1).  Tasks go to the ranks
+    of this build (one process per GPU) instead of a multiprocessing.Pool; results in task order."""
+    tasks = []
+    for a in fargs:
+        kw = dict(a[0] if isinstance(a, tuple) else a)
+        kw.pop('func', None)
+        tasks.append(kw)
+    imp = IterMP(njobs=njobs, run_async=run_async)
+    imp.run(func, {}, tasks)
+    return imp.output
+
+
+def test_IMP(iter_arg, fixed_arg):
+    """The reference's self-test task (parallel.py:72-77): returns its first argument."""
+    return iter_arg
+
+
 class IterMP:
     """`IterMP(njobs=None, run_async=False).run(func, fargs={}, step_args=None)`; results of
     all tasks, in task order, in `.output` (reference parallel.py:36-68)."""

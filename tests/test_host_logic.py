@@ -607,3 +607,13 @@ def test_five_stage_pipeline_with_bounded_buffer_sets_and_abort():
         run_shard(func, tasks, list(range(12)))
     assert 'boom 5' in str(e.value) and abort.is_set()
     assert time.time() - t0 < 10
+
+
+def test_run_starmap_keeps_the_reference_call_forms():
+    """parallel.run_starmap / starmap_helper / test_IMP under the reference's names (parallel.py:12-32, 72-77)."""
+    from pgw4era5_amd import parallel as P
+    serial = P.run_starmap(P.test_IMP, [dict(iter_arg=i, fixed_arg='x') for i in range(4)], njobs=1)
+    assert serial == [0, 1, 2, 3]
+    wrapped = [(dict(iter_arg=i, fixed_arg='x', func=P.test_IMP),) for i in range(3)]      # the njobs > 1 form of IterMP.run
+    assert P.run_starmap(P.test_IMP, wrapped, njobs=1) == [0, 1, 2]
+    assert P.starmap_helper(dict(func=P.test_IMP, iter_arg=7, fixed_arg=None)) == 7
