@@ -873,40 +873,52 @@ def _band(case, np, j0, rows):
 
 
 def _cpu_worker(args):
-    """One worker of the file-parallel leg: the oracle on its own latitude band (reference: one file per pool worker,
-    parallel.py:20-27); returns (seconds, passes)."""
+    """One worker of the file-parallel leg: the oracle (serial C column loops) on its own latitude band (reference: one
+    file per pool worker, parallel.py:20-27); returns (seconds, passes)."""
     import numpy as np
-    from oracle import pgw_oracle as O
+    from oracle import pgw_oracle as O, pgw_oracle_c as C
     j0, rows = args
     case = _CPU_CASE
     era, deltas = _band(case, np, j0, rows)
     t0 = time.perf_counter()
-    out = O.pgw_for_era5_arrays(era, deltas, case['delta_times'], case['plev'], case['target_dt'], ignore_top_pressure_error=True)
+    out = O.pgw_for_era5_arrays(era, deltas, case['delta_times'], case['plev'], case['target_dt'], ignore_top_pressure_error=True,
+                                vert_interp=C.vert_interp_delta)
     return time.perf_counter() - t0, out['n_iter']
 
 
 def cpu_baseline(case, a, np):
-    """The numpy oracle (a port: the reference's xarray/numba stack is not installable here) on latitude bands of the
-    same synthetic file, scaled to files/hour: (1) one process = the reference's default `-p 1`
-    (step_03_apply_to_era.py:542), `value`; (2) `procs` processes at once, each on its own band = the reference's
-    file-parallel `-p N` (parallel.py:20-27), `parallel`.  Fully vectorised numpy over the band, not the reference's
-    per-column numba / np.vectorize loops (those cannot run here), so it flatters the CPU side."""
+    """The CPU oracle (a port: the reference's xarray/numba stack is not installable here) on latitude bands of the
+    same synthetic file, scaled to files/hour.  One process = the reference's default `-p 1`
+    (step_03_apply_to_era.py:542) in two forms: (a) `c_column_loops` - the reference's serial per-column loops
+    (numba interp_1d_for_timelatlon, the np.vectorize'd replace_delta_sfc) as plain C -O2, the rest level-wise numpy like
+    the reference; (b) `numpy_vectorised` - the same with those loops vectorised over columns.
+    `value` = the faster of the two.  Then `procs` processes at once, each on its own band = the reference's file-parallel
+    `-p N` (parallel.py:20-27), `parallel` (form a).  Both forms are kinder to the CPU than the reference's own stack
+    (its np.vectorize is one Python call per column), which cannot run here."""
     global _CPU_CASE
     import multiprocessing as mp
-    from oracle import pgw_oracle as O
+    from oracle import pgw_oracle as O, pgw_oracle_c as C
+    C.lib()
     rows = min(a.cpu_rows, a.nlat)
     j0 = max((a.nlat - rows) // 2, 0)
     era, deltas = _band(case, np, j0, rows)
-    t0 = time.perf_counter()
-    out = O.pgw_for_era5_arrays(era, deltas, case['delta_times'], case['plev'], case['target_dt'],
-                                ignore_top_pressure_error=True)
-    t = time.perf_counter() - t0
     frac = rows / a.nlat
-    res = {'value': round(3600.0 / (t / frac), 3), 'unit': 'files/hour', 'cores': 1, 'kind': 'port',
-           'sample': '%d of %d latitude rows (%d columns) of the same file through oracle/pgw_oracle.py '
-                     '(numpy fp64), %.1f s, %d iterations; host has %d cores'
-                     % (rows, a.nlat, rows * a.nlon, t, out['n_iter'], os.cpu_count())}
-    del era, deltas, out
+    legs = {}
+    for name, vi in (('c_column_loops', C.vert_interp_delta), ('numpy_vectorised', None)):
+        t0 = time.perf_counter()
+        out = O.pgw_for_era5_arrays(era, deltas, case['delta_times'], case['plev'], case['target_dt'],
+                                    ignore_top_pressure_error=True, vert_interp=vi)
+        t = time.perf_counter() - t0
+        legs[name] = {'files_per_hour': round(3600.0 / (t / frac), 3), 'seconds': round(t, 1), 'iterations': out['n_iter']}
+        del out
+    best = max(legs, key=lambda k: legs[k]['files_per_hour'])
+    res = {'value': legs[best]['files_per_hour'], 'unit': 'files/hour', 'cores': 1, 'kind': 'port',
+           'sample': '%d of %d latitude rows (%d columns) of the same file through oracle/pgw_oracle.py (numpy fp64) with the '
+                     'per-column loops %s, %.1f s, %d iterations; host has %d cores'
+                     % (rows, a.nlat, rows * a.nlon, 'in serial C (oracle/pgw_oracle_c.c)' if best == 'c_column_loops'
+                        else 'vectorised over columns', legs[best]['seconds'], legs[best]['iterations'], os.cpu_count()),
+           'one_process': legs}
+    del era, deltas
     procs = a.cpu_procs or min(os.cpu_count() or 1, 16)
     if procs > 1:
         prow = max(min(a.nlat // procs, 40), 1)            # ~4 s of work per process; 16 bands of 40 rows = 640 of 721 rows

@@ -730,8 +730,11 @@ def pgw_for_era5_arrays_reinterp(era, deltas, delta_times, plev, target_dt,
 
 
 def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt,
-                        ignore_top_pressure_error=False, p_ref=P_REF_INP):
+                        ignore_top_pressure_error=False, p_ref=P_REF_INP, vert_interp=None):
     """pgw_for_era5 (step_03:44-381) with i_reinterp = 0 and fixed p_ref on in-memory arrays.
+
+    vert_interp: another implementation of vert_interp_delta with the same arguments (the serial per-column C
+    loops of oracle/pgw_oracle_c.py instead of the column-vectorised numpy form; same bits).
 
     era: dict with ak,bk,[akm,bkm],PS,FIS,T,QV,U,V,T_SKIN,T_SO,FR_LAND,FR_SEA_ICE,soil1
     deltas: dict var -> array [12, (S,) lat, lon] for ta,hur,ua,va,zg,tas,hurs,ts,tos,siconc
@@ -769,7 +772,7 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt,
             dsfc = ld(var + 's'); psh = ld('ps_hist')
         else:
             dsfc = None; psh = None
-        dint = vert_interp_delta(d, plev, pa_era, dsfc, psh, ignore_top_pressure_error)
+        dint = (vert_interp or vert_interp_delta)(d, plev, pa_era, dsfc, psh, ignore_top_pressure_error)
         pgw[var] = era_fields[var] + dint
     plev = np.asarray(plev, dtype=np.float64)
     kref = np.nonzero(plev == p_ref)[0]

@@ -422,6 +422,10 @@ def test_bench_cpu_baseline_legs():
     a = argparse.Namespace(cpu_rows=6, nlat=12, nlon=16, cpu_procs=2)
     res = bench.cpu_baseline(case, a, np)
     assert res['cores'] == 1 and res['kind'] == 'port' and res['value'] > 0
+    legs = res['one_process']
+    assert set(legs) == {'c_column_loops', 'numpy_vectorised'}
+    assert legs['c_column_loops']['iterations'] == legs['numpy_vectorised']['iterations']
+    assert res['value'] == max(l['files_per_hour'] for l in legs.values())
     assert res['parallel']['cores'] == 2 and res['parallel']['value'] > 0
 
 
