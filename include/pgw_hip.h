@@ -218,6 +218,16 @@ int pgw_reinterp_field(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long 
                        const void *dsfc_a, const void *pshist_b, const void *pshist_a, const void *era_field,
                        const void *ps_era, const void *ps_pgw, int ignore_top, void *out);
 
+/* f3  the same for TWO variables that share both pressure axes - ta + hur (one ps_hist; step_03_apply_to_era.py:202-216)
+ * or ua + va (:330-343; dsfc_b = NULL) - in one kernel: one target logarithm per level, one source logarithm per level of
+ * the ERA column and one bracket search per axis serve both.  delta_b / delta_a / dsfc_b / dsfc_a / era_field / out are
+ * arrays of two device pointers (dsfc_b, dsfc_a, delta_a may be NULL as in pgw_reinterp_field); results are the bits of
+ * two pgw_reinterp_field calls. */
+int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol, const double *plev,
+                      const void *const *delta_b, const void *const *delta_a, double x_hi, double x_new,
+                      const void *const *dsfc_b, const void *const *dsfc_a, const void *pshist_b, const void *pshist_a,
+                      const void *const *era_field, const void *ps_era, const void *ps_pgw, int ignore_top, void *const *out);
+
 /* replace_delta_sfc(source_P, ps_hist, delta, delta_sfc)  functions.py:343-366, on many columns:
  * plev_asc (nplev, host, ascending); delta (ntime, nplev, ncol) in ascending order;
  * delta_sfc, ps_hist (ntime, ncol); outputs out_P, out_delta (ntime, nplev, ncol). */

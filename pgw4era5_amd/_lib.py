@@ -39,6 +39,7 @@ PGW_ERR_REDUCE = 20
 _vp, _i, _ll, _d, _sz = C.c_void_p, C.c_int, C.c_longlong, C.c_double, C.c_size_t
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
+_vpp = C.POINTER(C.c_void_p)          # array of device pointers
 
 # name -> (restype, argtypes); must list every symbol declared in include/pgw_hip.h
 SIGNATURES = {
@@ -80,6 +81,7 @@ SIGNATURES = {
     'pgw_vert_interp_delta': (_i, [_vp, _i, _i, _i, _i, _ll, _dp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _i, _vp, _vp]),
     'pgw_reinterp_field': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'pgw_reinterp_pair': (_i, [_vp, _i, _i, _i, _ll, _dp, _vpp, _vpp, _d, _d, _vpp, _vpp, _vp, _vp, _vpp, _vp, _vp, _i, _vpp]),
     'pgw_replace_delta_sfc': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _vp, _vp, _vp]),
     'pgw_integrate_tos': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp]),
     'pgw_adjust_ps_step': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _i, _dp]),

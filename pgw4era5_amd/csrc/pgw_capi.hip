@@ -763,6 +763,59 @@ extern "C" int pgw_reinterp_field(pgw_ctx *ctx, int dtype, int ntime, int nplev,
     return PGW_OK;
 }
 
+extern "C" int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol, const double *plev,
+                                 const void *const *delta_b, const void *const *delta_a, double x_hi, double x_new,
+                                 const void *const *dsfc_b, const void *const *dsfc_a, const void *pshist_b,
+                                 const void *pshist_a, const void *const *era_field, const void *ps_era, const void *ps_pgw,
+                                 int ignore_top, void *const *out) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nplev >= 2 && nplev <= MAX_PLEV, "nplev must be in [2, 64]");
+    NEED(ctx, plev && delta_b && era_field && ps_era && ps_pgw && out, "null pointer");
+    NEED(ctx, delta_b[0] && delta_b[1] && era_field[0] && era_field[1] && out[0] && out[1], "null pointer");
+    NEED(ctx, (dsfc_b == nullptr) == (pshist_b == nullptr), "delta_sfc and ps_hist must be given together");
+    NEED(ctx, !dsfc_b || (dsfc_b[0] && dsfc_b[1]), "null pointer");
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    const bool lerp = (x_hi != 0.0);
+    NEED(ctx, !lerp || (delta_a && delta_a[0] && delta_a[1] && (!dsfc_b || (dsfc_a && dsfc_a[0] && dsfc_a[1] && pshist_a))),
+         "the record after the instant is missing");
+    int rc = plev_table(ctx, nplev, plev);
+    if (rc) return rc;
+    if ((rc = status_reset(ctx))) return rc;
+    Levels lv = levels_of(ctx);
+    const long long total = (long long)ntime * ncol;
+    {
+        Prof pr(ctx, PGW_K_VERT_INTERP_DELTA);
+        DISPATCH_T(dtype, {
+            ReinterpPair<T> rv;
+            for (int v = 0; v < 2; ++v) {
+                rv.d[v] = DeltaSrc<T>{(const T *)delta_b[v], lerp ? (const T *)delta_a[v] : nullptr, x_hi, x_new};
+                rv.sfc[v] = DeltaSrc<T>{dsfc_b ? (const T *)dsfc_b[v] : nullptr, (dsfc_b && lerp) ? (const T *)dsfc_a[v] : nullptr, x_hi, x_new};
+                rv.era[v] = (const T *)era_field[v];
+                rv.out[v] = (T *)out[v];
+            }
+            DeltaSrc<T> p{(const T *)pshist_b, lerp ? (const T *)pshist_a : nullptr, x_hi, x_new};
+            if (dsfc_b)
+                hipLaunchKernelGGL((k_reinterp_pair<T, true>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, ctx->plev_tab,
+                                   lv, ntime, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, ignore_top ? 0 : 1, ctx->d_status);
+            else
+                hipLaunchKernelGGL((k_reinterp_pair<T, false>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, ctx->plev_tab,
+                                   lv, ntime, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, ignore_top ? 0 : 1, ctx->d_status);
+        });
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = status_check(ctx))) return rc;
+    if (!ignore_top) {                                     // functions.py:417-425
+        DevStatus *h = ctx->h_status;
+        if (!h->nan_seen && h->min_targ_bits != ~0ull && h->min_src_bits != ~0ull) {
+            double mt, ms;
+            memcpy(&mt, &h->min_targ_bits, 8);
+            memcpy(&ms, &h->min_src_bits, 8);
+            if (mt < ms) { ctx->err = status_text(PGW_ERR_TOP_PRESSURE); ctx->err_col = -1; return PGW_ERR_TOP_PRESSURE; }
+        }
+    }
+    return PGW_OK;
+}
+
 extern "C" int pgw_replace_delta_sfc(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol,
                                      const double *plev_asc, const void *delta, const void *delta_sfc,
                                      const void *ps_hist, void *out_P, void *out_delta) {

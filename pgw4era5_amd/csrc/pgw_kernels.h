@@ -985,6 +985,181 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_field(PlevTable pt, Levels l
     }
 }
 
+// settings.i_reinterp = 1, TWO variables that share both pressure axes in one kernel (ta + hur, whose surface insertion
+// uses the same ps_hist, or ua + va): per level ONE target logarithm, one source logarithm per window step, one bracket
+// search on each axis and one reciprocal per interval serve both variables (k_reinterp_field spends them per variable),
+// and the delta records of a bracket are cached like k_delta_quad's (a step to the next source level fetches one level,
+// not two; the constant ranges above / below the delta file's levels fetch nothing).  Quotients go through SharedDivisor
+// (the compiler's own division steps: same bits as k_reinterp_field's `/` for the finite, normal-range operands here).
+template <typename T>
+struct ReinterpPair {
+    DeltaSrc<T> d[2], sfc[2];
+    const T *era[2];
+    T *out[2];
+};
+
+template <typename T, bool HAS_SFC>
+__global__ __launch_bounds__(BLOCK) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol, ReinterpPair<T> rv,
+                                                         DeltaSrc<T> psh, const T *__restrict__ ps_era,
+                                                         const T *__restrict__ ps_pgw, int check_top, DevStatus *st) {
+    __shared__ double s_mint[BLOCK / 64], s_mins[BLOCK / 64];
+    __shared__ int s_nan[BLOCK / 64];
+    __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
+    const int S = pt.n, N = lv.nlev;
+    if (threadIdx.x < MAX_PLEV) {
+        s_p[threadIdx.x] = pt.p[threadIdx.x];
+        s_lnp[threadIdx.x] = pt.lnp[threadIdx.x];
+    }
+    __syncthreads();
+    long long flat = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    double min_t = __builtin_inf(), min_s = __builtin_inf();
+    int nanflag = 0;
+    if (flat < (long long)ntime * ncol) {
+        long long t = flat / ncol, c = flat - t * ncol;
+        const long long dbase = t * S * ncol + c;      // delta records are (ntime, S, ncol), file order
+        int ksfc = -1;                                 // level moved to ps_hist
+        bool fill_below = false;
+        double d_sfc0 = 0.0, d_sfc1 = 0.0, lnps = 0.0, pshv = 0.0;
+        if (HAS_SFC) {
+            bool bad = false;
+            pshv = psh.get(flat);
+            d_sfc0 = rv.sfc[0].get(flat);
+            d_sfc1 = rv.sfc[1].get(flat);
+            if (pshv > pt.pmax) {                                  // functions.py:356-359
+                ksfc = S - 1;
+            } else if (pshv < pt.pmin) {                           // :360-361
+                bad = true;
+            } else {                                               // :362-365
+                for (int i = 0; i < S; ++i) if (pshv > s_p[i]) ksfc = i;
+                if (ksfc < 0) bad = true;
+                fill_below = true;
+            }
+            if (bad) { report(st, 15, flat); ksfc = -1; }
+            lnps = pgw_log_tab(pshv, lt.logtab);
+        }
+        auto srcx = [&](int i) -> double { return (HAS_SFC && i == ksfc) ? lnps : s_lnp[i]; };
+        auto is_sfc = [&](int i) -> bool { return HAS_SFC && ksfc >= 0 && (i == ksfc || (fill_below && i > ksfc)); };
+        if (check_top) {
+            for (int i = 0; i < S; ++i) {                          // np.min(source_P) over this column (:417)
+                double p = (HAS_SFC && i == ksfc) ? pshv : s_p[i];
+                if (p != p) nanflag |= 2; else min_s = fmin(min_s, p);
+            }
+        }
+        // delta records of the bracket (ci, ci + 1) of both variables; all loads of a change before the first use
+        int ci = -2;
+        double a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+        auto fetch = [&](int i1) {
+            if (ci == i1) return;
+            const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
+            const long long oh = dbase + (long long)(S - 1 - ih) * ncol, ol = dbase + (long long)(S - 1 - i1) * ncol;
+            const bool seq = (ci + 1 == i1);
+            const bool need_h = !is_sfc(ih), need_l = !seq && !is_sfc(i1);
+            double h0 = 0, h1 = 0, l0 = 0, l1 = 0;
+            if (need_h) { h0 = rv.d[0].get(oh); h1 = rv.d[1].get(oh); }
+            if (need_l) { l0 = rv.d[0].get(ol); l1 = rv.d[1].get(ol); }
+            if (seq) { a_lo = a_hi; b_lo = b_hi; }
+            else { a_lo = need_l ? l0 : d_sfc0; b_lo = need_l ? l1 : d_sfc1; }
+            a_hi = need_h ? h0 : d_sfc0;
+            b_hi = need_h ? h1 : d_sfc1;
+            ci = i1;
+        };
+        const double pse = (double)ps_era[flat], psv = (double)ps_pgw[flat];
+        const long long obase = t * (long long)N * ncol + c;
+        const T *pf0 = rv.era[0] + obase, *pf1 = rv.era[1] + obase;
+        // ---- window over the ERA columns (see k_reinterp_field): level wj - 1, level wj, raw values of wj + 1 .. wj + 4 in flight
+        int wj;
+        double wxm = 0, wxj, um = 0, uj, vm = 0, vj, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+        auto lev_off = [&](int lev) -> long long { return (long long)(lev < N ? lev : N - 1) * ncol; };
+        auto wreset = [&]() {
+            wj = 0;
+            wxj = pgw_log_tab(lt.akm[0] + pse * lt.bkm[0], lt.logtab);
+            uj = (double)SIG_LD(pf0); vj = (double)SIG_LD(pf1);
+            qa0 = (double)SIG_LD(pf0 + lev_off(1)); qb0 = (double)SIG_LD(pf1 + lev_off(1));
+            qa1 = (double)SIG_LD(pf0 + lev_off(2)); qb1 = (double)SIG_LD(pf1 + lev_off(2));
+            qa2 = (double)SIG_LD(pf0 + lev_off(3)); qb2 = (double)SIG_LD(pf1 + lev_off(3));
+            qa3 = (double)SIG_LD(pf0 + lev_off(4)); qb3 = (double)SIG_LD(pf1 + lev_off(4));
+        };
+        wreset();
+        int j = 0;
+        double xprev = -__builtin_inf();
+        int wdiv = -1;                                  // window position by_W belongs to
+        SharedDivisor by_W(1.0, 1.0);
+        for (int l = 0; l < N; ++l) {
+            const double p = lt.akm[l] + psv * lt.bkm[l];                                   // step_03:196-197
+            if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
+            const double x = pgw_log_tab(p, lt.logtab);
+            if (__builtin_expect(!(x >= xprev), 0)) { j = 0; wreset(); wdiv = -1; }         // descending / NaN target: both scans restart
+            // -- the ERA fields at this pressure (interp_extrap_1d, 'constant')
+            while (wj < N && !(wxj == x || wxj > x)) {
+                wxm = wxj; um = uj; vm = vj;
+                ++wj;
+                if (wj < N) {
+                    wxj = pgw_log_tab(lt.akm[wj] + pse * lt.bkm[wj], lt.logtab);
+                    uj = qa0; qa0 = qa1; qa1 = qa2; qa2 = qa3;
+                    vj = qb0; qb0 = qb1; qb1 = qb2; qb2 = qb3;
+                    const long long o = lev_off(wj + 4);
+                    qa3 = (double)SIG_LD(pf0 + o); qb3 = (double)SIG_LD(pf1 + o);
+                }
+            }
+            double e0, e1;
+            if (wj >= N) { e0 = um; e1 = vm; }                      // beyond the last source level: its value   :558-560
+            else if (wxj == x || wj == 0) { e0 = uj; e1 = vj; }     // exact :540-543 / before the first: its value :534-536
+            else {                                                  // :575-578
+                if (wdiv != wj) { by_W = SharedDivisor(wxj - wxm); wdiv = wj; }
+                const double dx = x - wxm;
+                e0 = um + by_W.divide(dx * (uj - um));
+                e1 = vm + by_W.divide(dx * (vj - vm));
+            }
+            // -- the climate deltas at this pressure (as k_vert_interp_delta)
+            while (j < S) {
+                double xs = srcx(j);
+                if (xs == x || xs > x) break;
+                ++j;
+            }
+            int i1, i2;
+            if (j >= S) { i1 = i2 = S - 1; }
+            else {
+                double xs = srcx(j);
+                if (xs == x) { i1 = i2 = j; }
+                else if (j == 0) { i1 = i2 = 0; }
+                else { i1 = j - 1; i2 = j; }
+            }
+            fetch(i1);
+            double y0 = a_lo, y1 = b_lo;
+            if (i1 != i2) {
+                const double x1 = srcx(i1);
+                const SharedDivisor by_D(srcx(i2) - x1);
+                const double dx = x - x1;
+                y0 = a_lo + by_D.divide(dx * (a_hi - a_lo));
+                y1 = b_lo + by_D.divide(dx * (b_hi - b_lo));
+            }
+            const long long o = obase + (long long)l * ncol;
+            SIG_ST((T)(e0 + y0), rv.out[0] + o);                                            // vars_era + deltas  :216
+            SIG_ST((T)(e1 + y1), rv.out[1] + o);
+            xprev = (x == x) ? x : __builtin_inf();
+        }
+    }
+    if (check_top) {
+        double wt = wave_min(min_t), ws = wave_min(min_s);
+        int wn = nanflag;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wn |= __shfl_xor(wn, off, 64);
+        int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { s_mint[w] = wt; s_mins[w] = ws; s_nan[w] = wn; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mt = s_mint[0], ms = s_mins[0];
+            int nn = s_nan[0];
+            for (int i = 1; i < BLOCK / 64; ++i) { mt = fmin(mt, s_mint[i]); ms = fmin(ms, s_mins[i]); nn |= s_nan[i]; }
+            if (mt < __builtin_inf()) atomicMin(&st->min_targ_bits, mt > 0 ? dbits(mt) : 0ull);
+            if (ms < __builtin_inf()) atomicMin(&st->min_src_bits, ms > 0 ? dbits(ms) : 0ull);
+            if (nn) atomicOr(&st->nan_seen, nn);
+        }
+    }
+}
+
 // =====================================================================================
 // Fused per-file delta kernels (production path of pgw_step03_file).
 //
@@ -1215,6 +1390,9 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
 #ifndef QUAD_MINW
 #define QUAD_MINW 3
 #endif
+#ifndef QUAD_MINW_F32
+#define QUAD_MINW_F32 4
+#endif
 // TO = storage type of the 4-D outputs.  REF (reference-dtype mode; T = float, TO = double): what numpy's promotion
 // computes on float32 files - RELHUM of the ERA state through the float32 e_sat chain
 // (q_to_rh_f32), float32 record differences in the time interpolation, era (float32) + delta (float64) = float64 outputs.
@@ -1223,7 +1401,7 @@ __global__ __launch_bounds__(TPB, THERMO ? 4 : 1) void k_delta_pair(PlevTable pt
 #define QST st_off_nt
 #define QST2 st_off
 template <typename T, typename TO, int U, int TPB, typename O, bool LERP, bool REF>
-__global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
+__global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) void k_delta_quad(PlevTable pt, Levels lv, int ntime, long long ncol,
                                                        const T *__restrict__ fT, const T *__restrict__ fQ,
                                                        const T *__restrict__ fU, const T *__restrict__ fV,
                                                        const T *__restrict__ PS,
@@ -1368,21 +1546,21 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
         auto ydiff = [](double hi, double lo) -> double {
             return (REF && !LERP) ? (double)((float)hi - (float)lo) : hi - lo; };
         // ---- level loop, chunks of U levels with the next chunk's 4*U rows in flight
-        double nT[U], nQ[U], nU[U], nV[U];
+        T nT[U], nQ[U], nU[U], nV[U];                 // prefetched rows stay in the storage type until they are used
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             O o = base + (O)(u < N ? u : N - 1) * row;
-            nT[u] = (double)QLD(fT, o); nQ[u] = (double)QLD(fQ, o); nU[u] = (double)QLD(fU, o); nV[u] = (double)QLD(fV, o);
+            nT[u] = QLD(fT, o); nQ[u] = QLD(fQ, o); nU[u] = QLD(fU, o); nV[u] = QLD(fV, o);
         }
         for (int l0 = 0; l0 < N; l0 += U) {
-            double cT[U], cQ[U], cU[U], cV[U];
+            T cT[U], cQ[U], cU[U], cV[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { cT[u] = nT[u]; cQ[u] = nQ[u]; cU[u] = nU[u]; cV[u] = nV[u]; }
             if (l0 + U < N) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     O o = base + (O)((l0 + U + u) < N ? (l0 + U + u) : N - 1) * row;
-                    nT[u] = (double)QLD(fT, o); nQ[u] = (double)QLD(fQ, o); nU[u] = (double)QLD(fU, o); nV[u] = (double)QLD(fV, o);
+                    nT[u] = QLD(fT, o); nQ[u] = QLD(fQ, o); nU[u] = QLD(fU, o); nV[u] = QLD(fV, o);
                 }
             }
 #pragma unroll
@@ -1451,12 +1629,12 @@ __global__ __launch_bounds__(TPB, QUAD_MINW) void k_delta_quad(PlevTable pt, Lev
                         }
                     }
                     const O o = obase + (O)l * orow;
-                    QST(oU, o, (TO)(cU[u] + dc));                                  // step_03:170-173
-                    QST(oV, o, (TO)(cV[u] + dd));
+                    QST(oU, o, (TO)((double)cU[u] + dc));                                  // step_03:170-173
+                    QST(oV, o, (TO)((double)cV[u] + dd));
                     double rh_era;                                                 // step_03:91-94
                     if (REF) rh_era = q_to_rh_f32((float)cQ[u], pa, (float)cT[u]);
-                    else rh_era = q_to_rh(cQ[u], pa, cT[u]);
-                    double ta_pgw = cT[u] + da;
+                    else rh_era = q_to_rh((double)cQ[u], pa, (double)cT[u]);
+                    double ta_pgw = (double)cT[u] + da;
                     double hur_pgw = rh_era + db;
                     QST2(oT, o, (TO)ta_pgw);
                     double e_pgw = rh_to_e(hur_pgw, ta_pgw);                       // functions.py:123
