@@ -763,6 +763,27 @@ extern "C" int pgw_reinterp_field(pgw_ctx *ctx, int dtype, int ntime, int nplev,
     return PGW_OK;
 }
 
+template <typename T, bool SFC, typename O>
+static void launch_reinterp_pair_o(pgw_ctx *ctx, const Levels &lv, int ntime, long long ncol, const ReinterpPair<T> &rv,
+                                   const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, int check_top) {
+    hipLaunchKernelGGL((k_reinterp_pair<T, SFC, O>), dim3(nblocks((long long)ntime * ncol, BLOCK)), dim3(BLOCK),
+                       2 * lv.nlev * sizeof(double), ctx->stream, ctx->plev_tab, lv, ntime, ncol, rv, p, ps_era, ps_pgw,
+                       check_top, ctx->d_status);
+}
+template <typename T>
+static void launch_reinterp_pair(pgw_ctx *ctx, const Levels &lv, int ntime, int nplev, long long ncol, const ReinterpPair<T> &rv,
+                                 const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, bool sfc, int check_top) {
+    // 32-bit byte offsets when every array (fields: nlev levels, delta records: nplev levels) is smaller than 4 GiB
+    const unsigned long long big = (unsigned long long)ntime * (lv.nlev > nplev ? lv.nlev : nplev) * ncol * sizeof(T);
+    if (big < (1ull << 32)) {
+        if (sfc) launch_reinterp_pair_o<T, true, boff32>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, false, boff32>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+    } else {
+        if (sfc) launch_reinterp_pair_o<T, true, boff64>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, false, boff64>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+    }
+}
+
 extern "C" int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol, const double *plev,
                                  const void *const *delta_b, const void *const *delta_a, double x_hi, double x_new,
                                  const void *const *dsfc_b, const void *const *dsfc_a, const void *pshist_b,
@@ -794,12 +815,8 @@ extern "C" int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, 
                 rv.out[v] = (T *)out[v];
             }
             DeltaSrc<T> p{(const T *)pshist_b, lerp ? (const T *)pshist_a : nullptr, x_hi, x_new};
-            if (dsfc_b)
-                hipLaunchKernelGGL((k_reinterp_pair<T, true>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, ctx->plev_tab,
-                                   lv, ntime, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, ignore_top ? 0 : 1, ctx->d_status);
-            else
-                hipLaunchKernelGGL((k_reinterp_pair<T, false>), dim3(nblocks(total, BLOCK)), dim3(BLOCK), 0, ctx->stream, ctx->plev_tab,
-                                   lv, ntime, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, ignore_top ? 0 : 1, ctx->d_status);
+            launch_reinterp_pair<T>(ctx, lv, ntime, nplev, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, dsfc_b != nullptr,
+                                    ignore_top ? 0 : 1);
         });
     }
     HIPCHK(ctx, hipGetLastError());

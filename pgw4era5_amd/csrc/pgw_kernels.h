@@ -684,6 +684,14 @@ struct DeltaSrc {
         const double diff = REF ? (double)(T)(ra - rb) : (double)ra - (double)rb;
         return diff / x_hi * x_new + (double)rb;                  // :288-292 (scipy interp1d linear)
     }
+    // get() addressed by byte offset (ld_off)
+    template <typename O>
+    __device__ __forceinline__ double get_off(O byte_off) const {
+        const T rb = ld_off(b, byte_off);
+        if (!a) return (double)rb;
+        const T ra = ld_off(a, byte_off);
+        return ((double)ra - (double)rb) / x_hi * x_new + (double)rb;
+    }
     // same, addressed by byte offset (ld_off); the division by the kernel-wide x_hi goes through a reciprocal the
     // caller computed once (SharedDivisor: same quotient bits)
     // LERP is the compile-time form of `a != nullptr` (all records of a file share the instant, so it is one
@@ -991,23 +999,40 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_field(PlevTable pt, Levels l
 // and the delta records of a bracket are cached like k_delta_quad's (a step to the next source level fetches one level,
 // not two; the constant ranges above / below the delta file's levels fetch nothing).  Quotients go through SharedDivisor
 // (the compiler's own division steps: same bits as k_reinterp_field's `/` for the finite, normal-range operands here).
+//
+// The ERA columns are streamed with a STATIC schedule - at target level l the row of level l + 8 is requested and the
+// row of level l + 4 (requested four levels earlier) is put into a per-thread LDS ring of 8 levels - and the window that
+// follows the source axis reads its values from the ring by level index.  k_reinterp_field moves the window through
+// registers inside its data-dependent `while` loop (value rotation q0 <- q1 <- ...): every register copy has to wait for
+// the load it copies, so each level exposes a full memory latency (2 TB/s).  Here the loads are consumed by the ring
+// writes in issue order with four rows in flight, and the window's `while` loop only touches LDS.  A window position the
+// ring does not hold (the two surface pressures more than 3-4 levels apart, or a restart) reads global memory directly.
 template <typename T>
 struct ReinterpPair {
     DeltaSrc<T> d[2], sfc[2];
     const T *era[2];
     T *out[2];
 };
+constexpr int RING = 8, RING_LEAD = 4;
 
-template <typename T, bool HAS_SFC>
-__global__ __launch_bounds__(BLOCK) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol, ReinterpPair<T> rv,
-                                                         DeltaSrc<T> psh, const T *__restrict__ ps_era,
-                                                         const T *__restrict__ ps_pgw, int check_top, DevStatus *st) {
+#ifndef RP_MINW
+#define RP_MINW 4
+#endif
+// O: byte-offset type of ld_off / st_off (32-bit when every array is smaller than 4 GiB)
+template <typename T, bool HAS_SFC, typename O>
+__global__ __launch_bounds__(BLOCK, RP_MINW) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol, ReinterpPair<T> rv,
+                                                            DeltaSrc<T> psh, const T *__restrict__ ps_era,
+                                                            const T *__restrict__ ps_pgw, int check_top, DevStatus *st) {
+    extern __shared__ double lds_rp[];               // akm[N] | bkm[N]
     __shared__ double s_mint[BLOCK / 64], s_mins[BLOCK / 64];
     __shared__ int s_nan[BLOCK / 64];
     __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
-    __shared__ double s_lev[LEVTAB_DOUBLES];
-    LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
+    __shared__ double s_logt[2 * LOG_TABLE_N];
+    __shared__ T s_ring[2][RING][BLOCK];
     const int S = pt.n, N = lv.nlev;
+    double *s_akm = lds_rp, *s_bkm = lds_rp + N;
+    stage_log_table(s_logt, BLOCK);
+    for (int i = threadIdx.x; i < N; i += BLOCK) { s_akm[i] = lv.akm[i]; s_bkm[i] = lv.bkm[i]; }
     if (threadIdx.x < MAX_PLEV) {
         s_p[threadIdx.x] = pt.p[threadIdx.x];
         s_lnp[threadIdx.x] = pt.lnp[threadIdx.x];
@@ -1018,7 +1043,8 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_pair(PlevTable pt, Levels lv
     int nanflag = 0;
     if (flat < (long long)ntime * ncol) {
         long long t = flat / ncol, c = flat - t * ncol;
-        const long long dbase = t * S * ncol + c;      // delta records are (ntime, S, ncol), file order
+        const O row = (O)((unsigned long long)ncol * sizeof(T));
+        const O dbase = (O)((unsigned long long)(t * S * ncol + c) * sizeof(T));      // delta records are (ntime, S, ncol), file order
         int ksfc = -1;                                 // level moved to ps_hist
         bool fill_below = false;
         double d_sfc0 = 0.0, d_sfc1 = 0.0, lnps = 0.0, pshv = 0.0;
@@ -1037,7 +1063,7 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_pair(PlevTable pt, Levels lv
                 fill_below = true;
             }
             if (bad) { report(st, 15, flat); ksfc = -1; }
-            lnps = pgw_log_tab(pshv, lt.logtab);
+            lnps = pgw_log_tab(pshv, s_logt);
         }
         auto srcx = [&](int i) -> double { return (HAS_SFC && i == ksfc) ? lnps : s_lnp[i]; };
         auto is_sfc = [&](int i) -> bool { return HAS_SFC && ksfc >= 0 && (i == ksfc || (fill_below && i > ksfc)); };
@@ -1053,12 +1079,12 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_pair(PlevTable pt, Levels lv
         auto fetch = [&](int i1) {
             if (ci == i1) return;
             const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
-            const long long oh = dbase + (long long)(S - 1 - ih) * ncol, ol = dbase + (long long)(S - 1 - i1) * ncol;
+            const O oh = dbase + (O)(S - 1 - ih) * row, ol = dbase + (O)(S - 1 - i1) * row;
             const bool seq = (ci + 1 == i1);
             const bool need_h = !is_sfc(ih), need_l = !seq && !is_sfc(i1);
             double h0 = 0, h1 = 0, l0 = 0, l1 = 0;
-            if (need_h) { h0 = rv.d[0].get(oh); h1 = rv.d[1].get(oh); }
-            if (need_l) { l0 = rv.d[0].get(ol); l1 = rv.d[1].get(ol); }
+            if (need_h) { h0 = rv.d[0].get_off(oh); h1 = rv.d[1].get_off(oh); }
+            if (need_l) { l0 = rv.d[0].get_off(ol); l1 = rv.d[1].get_off(ol); }
             if (seq) { a_lo = a_hi; b_lo = b_hi; }
             else { a_lo = need_l ? l0 : d_sfc0; b_lo = need_l ? l1 : d_sfc1; }
             a_hi = need_h ? h0 : d_sfc0;
@@ -1066,79 +1092,100 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_pair(PlevTable pt, Levels lv
             ci = i1;
         };
         const double pse = (double)ps_era[flat], psv = (double)ps_pgw[flat];
-        const long long obase = t * (long long)N * ncol + c;
-        const T *pf0 = rv.era[0] + obase, *pf1 = rv.era[1] + obase;
-        // ---- window over the ERA columns (see k_reinterp_field): level wj - 1, level wj, raw values of wj + 1 .. wj + 4 in flight
+        const O obase = (O)((unsigned long long)(t * (long long)N * ncol + c) * sizeof(T));
+        const T *pf0 = rv.era[0], *pf1 = rv.era[1];
+        auto lev_off = [&](int lev) -> O { return obase + (O)(lev < N ? lev : N - 1) * row; };
+        // ---- the ring: at target level l it holds the ERA levels [l - 3, l + 5)
+        const int tid = threadIdx.x;
+        int ring_lo = 0;                                               // l - 3 (may be negative)
+        auto era_at = [&](int lev, double &u, double &v) {
+            if ((unsigned)(lev - ring_lo) < (unsigned)RING) { u = (double)s_ring[0][lev & (RING - 1)][tid]; v = (double)s_ring[1][lev & (RING - 1)][tid]; }
+            else { const O o = lev_off(lev); u = (double)ld_off(pf0, o); v = (double)ld_off(pf1, o); }
+        };
+        T na[RING_LEAD], nb[RING_LEAD];                                 // rows in flight: levels l + 4 .. l + 7 at the top of level l
+        {
+            T ia[RING_LEAD], ib[RING_LEAD];
+#pragma unroll
+            for (int u = 0; u < RING_LEAD; ++u) { ia[u] = ld_off_nt(pf0, lev_off(u)); ib[u] = ld_off_nt(pf1, lev_off(u)); }
+#pragma unroll
+            for (int u = 0; u < RING_LEAD; ++u) { na[u] = ld_off_nt(pf0, lev_off(RING_LEAD + u)); nb[u] = ld_off_nt(pf1, lev_off(RING_LEAD + u)); }
+#pragma unroll
+            for (int u = 0; u < RING_LEAD; ++u) { s_ring[0][u][tid] = ia[u]; s_ring[1][u][tid] = ib[u]; }
+        }
+        // ---- window over the source axis: level wj - 1 (wxm, um, vm) and level wj (wxj, uj, vj)
         int wj;
-        double wxm = 0, wxj, um = 0, uj, vm = 0, vj, qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
-        auto lev_off = [&](int lev) -> long long { return (long long)(lev < N ? lev : N - 1) * ncol; };
+        double wxm = 0, wxj, um = 0, uj, vm = 0, vj;
         auto wreset = [&]() {
             wj = 0;
-            wxj = pgw_log_tab(lt.akm[0] + pse * lt.bkm[0], lt.logtab);
-            uj = (double)SIG_LD(pf0); vj = (double)SIG_LD(pf1);
-            qa0 = (double)SIG_LD(pf0 + lev_off(1)); qb0 = (double)SIG_LD(pf1 + lev_off(1));
-            qa1 = (double)SIG_LD(pf0 + lev_off(2)); qb1 = (double)SIG_LD(pf1 + lev_off(2));
-            qa2 = (double)SIG_LD(pf0 + lev_off(3)); qb2 = (double)SIG_LD(pf1 + lev_off(3));
-            qa3 = (double)SIG_LD(pf0 + lev_off(4)); qb3 = (double)SIG_LD(pf1 + lev_off(4));
+            wxj = pgw_log_tab(s_akm[0] + pse * s_bkm[0], s_logt);
+            era_at(0, uj, vj);
         };
-        wreset();
         int j = 0;
         double xprev = -__builtin_inf();
         int wdiv = -1;                                  // window position by_W belongs to
         SharedDivisor by_W(1.0, 1.0);
-        for (int l = 0; l < N; ++l) {
-            const double p = lt.akm[l] + psv * lt.bkm[l];                                   // step_03:196-197
-            if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
-            const double x = pgw_log_tab(p, lt.logtab);
-            if (__builtin_expect(!(x >= xprev), 0)) { j = 0; wreset(); wdiv = -1; }         // descending / NaN target: both scans restart
-            // -- the ERA fields at this pressure (interp_extrap_1d, 'constant')
-            while (wj < N && !(wxj == x || wxj > x)) {
-                wxm = wxj; um = uj; vm = vj;
-                ++wj;
-                if (wj < N) {
-                    wxj = pgw_log_tab(lt.akm[wj] + pse * lt.bkm[wj], lt.logtab);
-                    uj = qa0; qa0 = qa1; qa1 = qa2; qa2 = qa3;
-                    vj = qb0; qb0 = qb1; qb1 = qb2; qb2 = qb3;
-                    const long long o = lev_off(wj + 4);
-                    qa3 = (double)SIG_LD(pf0 + o); qb3 = (double)SIG_LD(pf1 + o);
+        for (int l0 = 0; l0 < N; l0 += RING_LEAD) {
+#pragma unroll
+            for (int u = 0; u < RING_LEAD; ++u) {
+                const int l = l0 + u;
+                if (l < N) {
+                    // row l + 4 into the ring (it replaces level l - 4), row l + 8 requested
+                    s_ring[0][(l + RING_LEAD) & (RING - 1)][tid] = na[u];
+                    s_ring[1][(l + RING_LEAD) & (RING - 1)][tid] = nb[u];
+                    ring_lo = l + RING_LEAD + 1 - RING;
+                    { const O o = lev_off(l + 2 * RING_LEAD); na[u] = ld_off_nt(pf0, o); nb[u] = ld_off_nt(pf1, o); }
+                    if (l == 0) wreset();
+                    const double p = s_akm[l] + psv * s_bkm[l];                                 // step_03:196-197
+                    if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
+                    const double x = pgw_log_tab(p, s_logt);
+                    if (__builtin_expect(!(x >= xprev), 0)) { j = 0; wreset(); wdiv = -1; }     // descending / NaN target: both scans restart
+                    // -- the ERA fields at this pressure (interp_extrap_1d, 'constant')
+                    while (wj < N && !(wxj == x || wxj > x)) {
+                        wxm = wxj; um = uj; vm = vj;
+                        ++wj;
+                        if (wj < N) {
+                            wxj = pgw_log_tab(s_akm[wj] + pse * s_bkm[wj], s_logt);
+                            era_at(wj, uj, vj);
+                        }
+                    }
+                    double e0, e1;
+                    if (wj >= N) { e0 = um; e1 = vm; }                      // beyond the last source level: its value   :558-560
+                    else if (wxj == x || wj == 0) { e0 = uj; e1 = vj; }     // exact :540-543 / before the first: its value :534-536
+                    else {                                                  // :575-578
+                        if (wdiv != wj) { by_W = SharedDivisor(wxj - wxm); wdiv = wj; }
+                        const double dx = x - wxm;
+                        e0 = um + by_W.divide(dx * (uj - um));
+                        e1 = vm + by_W.divide(dx * (vj - vm));
+                    }
+                    // -- the climate deltas at this pressure (as k_vert_interp_delta)
+                    while (j < S) {
+                        double xs = srcx(j);
+                        if (xs == x || xs > x) break;
+                        ++j;
+                    }
+                    int i1, i2;
+                    if (j >= S) { i1 = i2 = S - 1; }
+                    else {
+                        double xs = srcx(j);
+                        if (xs == x) { i1 = i2 = j; }
+                        else if (j == 0) { i1 = i2 = 0; }
+                        else { i1 = j - 1; i2 = j; }
+                    }
+                    fetch(i1);
+                    double y0 = a_lo, y1 = b_lo;
+                    if (i1 != i2) {
+                        const double x1 = srcx(i1);
+                        const SharedDivisor by_D(srcx(i2) - x1);
+                        const double dx = x - x1;
+                        y0 = a_lo + by_D.divide(dx * (a_hi - a_lo));
+                        y1 = b_lo + by_D.divide(dx * (b_hi - b_lo));
+                    }
+                    const O o = obase + (O)l * row;
+                    st_off_nt(rv.out[0], o, (T)(e0 + y0));                                      // vars_era + deltas  :216
+                    st_off_nt(rv.out[1], o, (T)(e1 + y1));
+                    xprev = (x == x) ? x : __builtin_inf();
                 }
             }
-            double e0, e1;
-            if (wj >= N) { e0 = um; e1 = vm; }                      // beyond the last source level: its value   :558-560
-            else if (wxj == x || wj == 0) { e0 = uj; e1 = vj; }     // exact :540-543 / before the first: its value :534-536
-            else {                                                  // :575-578
-                if (wdiv != wj) { by_W = SharedDivisor(wxj - wxm); wdiv = wj; }
-                const double dx = x - wxm;
-                e0 = um + by_W.divide(dx * (uj - um));
-                e1 = vm + by_W.divide(dx * (vj - vm));
-            }
-            // -- the climate deltas at this pressure (as k_vert_interp_delta)
-            while (j < S) {
-                double xs = srcx(j);
-                if (xs == x || xs > x) break;
-                ++j;
-            }
-            int i1, i2;
-            if (j >= S) { i1 = i2 = S - 1; }
-            else {
-                double xs = srcx(j);
-                if (xs == x) { i1 = i2 = j; }
-                else if (j == 0) { i1 = i2 = 0; }
-                else { i1 = j - 1; i2 = j; }
-            }
-            fetch(i1);
-            double y0 = a_lo, y1 = b_lo;
-            if (i1 != i2) {
-                const double x1 = srcx(i1);
-                const SharedDivisor by_D(srcx(i2) - x1);
-                const double dx = x - x1;
-                y0 = a_lo + by_D.divide(dx * (a_hi - a_lo));
-                y1 = b_lo + by_D.divide(dx * (b_hi - b_lo));
-            }
-            const long long o = obase + (long long)l * ncol;
-            SIG_ST((T)(e0 + y0), rv.out[0] + o);                                            // vars_era + deltas  :216
-            SIG_ST((T)(e1 + y1), rv.out[1] + o);
-            xprev = (x == x) ? x : __builtin_inf();
         }
     }
     if (check_top) {

@@ -279,16 +279,21 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     delta_ps, adj_ps = ctx.zeros(PS.shape, f64), ctx.zeros(PS.shape, f64)        # :182-184
     ps_pgw = buf('PS', PS.shape)
 
-    def reinterp(var, era_field, target):
-        """interp_logp_4d(era, pa_era, pa_pgw, 'constant') + load_delta_interp(var, pa_pgw)  :209-216, one kernel"""
-        if var in ('ta', 'hur'):
-            sfc, psh = dev[var + 's'], dev['ps_hist']
-            sb, sa, pb, pa_ = sfc.slab(rb).ptr, sfc.slab(ra).ptr, psh.slab(rb).ptr, psh.slab(ra).ptr
+    def reinterp_pair(var0, var1, era0, era1, target0, target1):
+        """interp_logp_4d(era, pa_era, pa_pgw, 'constant') + load_delta_interp(var, pa_pgw)  :209-216 for two variables on
+        the same axes (ta + hur: one ps_hist; ua + va), one kernel"""
+        def arr(*ptrs):
+            return (C.c_void_p * 2)(*[p.ptr if hasattr(p, 'ptr') else p for p in ptrs])
+        if var0 in ('ta', 'hur'):
+            sb = arr(dev[var0 + 's'].slab(rb), dev[var1 + 's'].slab(rb))
+            sa = arr(dev[var0 + 's'].slab(ra), dev[var1 + 's'].slab(ra))
+            pb, pa_ = dev['ps_hist'].slab(rb).ptr, dev['ps_hist'].slab(ra).ptr
         else:
             sb = sa = pb = pa_ = None
-        ctx._check(lib.pgw_reinterp_field(h, tag, nt, len(plev), ncol, plev.ctypes.data_as(_dp),
-                                          dev[var].slab(rb).ptr, dev[var].slab(ra).ptr, x_hi, x_new, sb, sa, pb, pa_,
-                                          era_field.ptr, PS.ptr, ps_pgw.ptr, 1 if ignore_top_pressure_error else 0, target.ptr))
+        ctx._check(lib.pgw_reinterp_pair(h, tag, nt, len(plev), ncol, plev.ctypes.data_as(_dp),
+                                         arr(dev[var0].slab(rb), dev[var1].slab(rb)), arr(dev[var0].slab(ra), dev[var1].slab(ra)),
+                                         x_hi, x_new, sb, sa, pb, pa_, arr(era0, era1), PS.ptr, ps_pgw.ptr,
+                                         1 if ignore_top_pressure_error else 0, arr(target0, target1)))
 
     ta_pgw, hur_pgw = buf('T', T.shape), buf('_hur_pgw', T.shape)
     err = np.inf
@@ -297,8 +302,7 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     max_err = C.c_double()
     while err > S.thresh_phi_ref_max_error:                                       # :189
         ctx._check(lib.pgw_update_ps(h, tag, n2, PS.ptr, delta_ps.ptr, adj_ps.ptr, ps_pgw.ptr))   # :192-193
-        reinterp('ta', T, ta_pgw)
-        reinterp('hur', relhum, hur_pgw)
+        reinterp_pair('ta', 'hur', T, relhum, ta_pgw, hur_pgw)
         ctx._check(lib.pgw_adjust_ps_step(h, tag, nt, ncol, ta_pgw.ptr, hur_pgw.ptr, PS.ptr, FIS.ptr, phi_era.ptr,
                                           dphi.ptr, delta_ps.ptr, adj_ps.ptr, float(p_ref), None, float(S.adj_factor), 0,
                                           C.byref(max_err)))
@@ -307,8 +311,7 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
         it += 1
         if it > S.max_n_iter:                                                     # :313-319
             raise ValueError('ERROR! Pressure adjustment did not converge')
-    reinterp('ua', era['U'], buf('U', T.shape))                                   # :330-343
-    reinterp('va', era['V'], buf('V', T.shape))
+    reinterp_pair('ua', 'va', era['U'], era['V'], buf('U', T.shape), buf('V', T.shape))   # :330-343
     ctx._check(lib.pgw_relative_to_specific_humidity_hybrid(h, tag, nt, ncol, hur_pgw.ptr, ps_pgw.ptr, ta_pgw.ptr,
                                                             buf('QV', T.shape).ptr))   # hus of the last pass, :262-266,370
     if 'FR_SEA_ICE' in era and 'siconc' in dev:                                   # surface riders :103-146

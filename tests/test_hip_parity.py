@@ -777,6 +777,64 @@ def test_reinterp_field_kernel_vs_oracle_composition(with_sfc):
     assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_reinterp_pair_is_two_reinterp_fields_bit_for_bit(dtype):
+    """pgw_reinterp_pair (ta + hur with the surface insertion, ua + va without) == two pgw_reinterp_field calls, bit for bit:
+    surface pressures +-8 % apart, a time-interpolated instant and an exact record, a column with a NaN surface pressure
+    (both scans restart) and ps_hist above / inside / at the edge of the delta levels."""
+    import ctypes as C
+    from pgw4era5_amd.device import default_context, dtype_tag
+    ctx = default_context()
+    c = _case(7, 9, 23, seed=35, dtype=dtype)
+    era, d = c['era'], c['deltas']
+    ctx.set_levels(era['ak'], era['bk'])
+    rng = np.random.default_rng(6)
+    ps_era = era['PS'].copy()
+    ps_pgw = (ps_era * (1 + 0.08 * (2 * rng.random(ps_era.shape) - 1))).astype(dtype)
+    ps_pgw[0, 2, 3] = np.nan
+    psh = d['ps_hist'].copy()
+    psh[:, 0, 0] = 103000.0                 # above every delta level: the last level moves
+    psh[:, 0, 1] = 70010.0                  # inside
+    nt, N, nlat, nlon = era['T'].shape
+    ncol = nlat * nlon
+    plev = np.ascontiguousarray(c['plev'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    tag = dtype_tag(np.dtype(dtype))
+    up = lambda v: ctx.to_device(np.ascontiguousarray(v, dtype=dtype))
+    pe, pp = up(ps_era), up(ps_pgw)
+    arr = lambda a, b: (C.c_void_p * 2)(a.ptr, b.ptr)
+    for (v0, v1, f0, f1, with_sfc) in (('ta', 'hur', era['T'], era['QV'] * 1e4, True), ('ua', 'va', era['U'], era['V'], False)):
+        for rb, ra, x_hi, x_new in ((3, 3, 0.0, 0.0), (3, 4, 31.0, 11.5)):
+            D = {k: up(v) for k, v in dict(f0=f0, f1=f1, b0=d[v0][rb], a0=d[v0][ra], b1=d[v1][rb], a1=d[v1][ra]).items()}
+            if with_sfc:
+                D.update({k: up(v) for k, v in dict(s0b=d[v0 + 's'][rb], s0a=d[v0 + 's'][ra], s1b=d[v1 + 's'][rb],
+                                                    s1a=d[v1 + 's'][ra], hb=psh[rb], ha=psh[ra]).items()})
+            single = []
+            for i in (0, 1):
+                out = ctx.empty(era['T'].shape, dtype)
+                sfc = (D['s%db' % i].ptr, D['s%da' % i].ptr, D['hb'].ptr, D['ha'].ptr) if with_sfc else (None,) * 4
+                ctx._check(ctx.lib.pgw_reinterp_field(ctx.handle, tag, nt, len(plev), ncol, plev.ctypes.data_as(dp), D['b%d' % i].ptr,
+                                                      D['a%d' % i].ptr, x_hi, x_new, *sfc, D['f%d' % i].ptr, pe.ptr, pp.ptr, 1, out.ptr))
+                single.append(out.numpy())
+            o0, o1 = ctx.empty(era['T'].shape, dtype), ctx.empty(era['T'].shape, dtype)
+            sfc = (arr(D['s0b'], D['s1b']), arr(D['s0a'], D['s1a']), D['hb'].ptr, D['ha'].ptr) if with_sfc else (None,) * 4
+            ctx._check(ctx.lib.pgw_reinterp_pair(ctx.handle, tag, nt, len(plev), ncol, plev.ctypes.data_as(dp), arr(D['b0'], D['b1']),
+                                                 arr(D['a0'], D['a1']), x_hi, x_new, *sfc, arr(D['f0'], D['f1']), pe.ptr, pp.ptr, 1,
+                                                 arr(o0, o1)))
+            np.testing.assert_array_equal(o0.numpy(), single[0])
+            np.testing.assert_array_equal(o1.numpy(), single[1])
+    # the model-top check of vert_interp_delta (functions.py:417-425); a NaN in the target pressures makes numpy's
+    # comparison False (no error), so this one runs on the NaN-free surface pressures
+    ctx._check(ctx.lib.pgw_reinterp_pair(ctx.handle, tag, nt, len(plev), ncol, plev.ctypes.data_as(dp), arr(D['b0'], D['b1']),
+                                         arr(D['a0'], D['a1']), 0.0, 0.0, None, None, None, None, arr(D['f0'], D['f1']), pe.ptr,
+                                         pp.ptr, 0, arr(o0, o1)))
+    with pytest.raises(ValueError) as e:
+        ctx._check(ctx.lib.pgw_reinterp_pair(ctx.handle, tag, nt, len(plev), ncol, plev.ctypes.data_as(dp), arr(D['b0'], D['b1']),
+                                             arr(D['a0'], D['a1']), 0.0, 0.0, None, None, None, None, arr(D['f0'], D['f1']), pe.ptr,
+                                             pe.ptr, 0, arr(o0, o1)))
+    assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
+
+
 def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
     """it > max_n_iter raises even if that pass converged (step_03:313-319)."""
     from pgw4era5_amd import step_03_apply_to_era as s3
