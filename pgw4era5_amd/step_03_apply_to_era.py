@@ -275,8 +275,12 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
         ctx._check(lib.pgw_memcpy_d2d(h, dzg.ptr, zb.ptr, zb.nbytes))
     else:
         ctx._check(lib.pgw_time_lerp(h, tag, zb.size, zb.ptr, za.ptr, x_hi, x_new, dzg.ptr))
-    dphi = ctx.to_device(dzg.numpy().astype(np.float64) * CON_G, f64)          # step_03:292-293 (2-D, once)
-    delta_ps, adj_ps = ctx.zeros(PS.shape, f64), ctx.zeros(PS.shape, f64)        # :182-184
+    # loop state in buffers that live across files (a hipMalloc / hipFree per file synchronises the device)
+    dphi = buf('_dphi', PS.shape, f64)
+    dphi.copy_from(dzg.numpy().astype(np.float64) * CON_G)                        # step_03:292-293 (2-D, once)
+    delta_ps, adj_ps = buf('_delta_ps', PS.shape, f64), buf('_adj_ps', PS.shape, f64)
+    for x in (delta_ps, adj_ps):                                                  # :182-184
+        ctx._check(lib.pgw_memset(h, x.ptr, 0, x.nbytes))
     ps_pgw = buf('PS', PS.shape)
 
     def reinterp_pair(var0, var1, era0, era1, target0, target1):
@@ -323,8 +327,6 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
             deltas.lerp2d('ts', target_dt, buf('_dts', s3)).ptr, era['FR_LAND'].ptr, deltas.ts_clim.ptr,
             era['T_SKIN'].ptr, era['T_SO'].ptr, buf('FR_SEA_ICE', s3).ptr, buf('_dts_comb', s3).ptr,
             buf('T_SKIN', s3).ptr, buf('T_SO', era['T_SO'].shape).ptr))
-    for x in (dphi, delta_ps, adj_ps):
-        x.free()
     return out, dict(n_iter=it - 1, max_err=hist, levels_touched=0)
 
 
