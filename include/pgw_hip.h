@@ -77,7 +77,9 @@ enum pgw_option {
                                  on chip; 0: one launch per pass                                                 [PGW_MULTIPASS]   */
     PGW_OPT_LOOP_GUESS = 4,   /* passes the next file's first multi-pass launch runs (1..8); updated by every file to its own pass
                                  count (consecutive ERA5 files of a run need the same number); initial value 6                  */
-    PGW_OPT_COUNT = 5
+    PGW_OPT_FORCE_OFF64 = 5,  /* 1: the 64-bit byte-offset instantiations of the kernels that address arrays below 4 GiB with
+                                 32-bit offsets (k_delta_quad, k_reinterp_pair) - test knob: the path a 0.125 deg L137 file takes    */
+    PGW_OPT_COUNT = 6
 };
 
 /* ---------------------------------------------------------------- context ------------ */

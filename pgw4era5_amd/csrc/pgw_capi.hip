@@ -240,6 +240,7 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
     c->opt[PGW_OPT_FORCE_VEC1] = env_flag("PGW_FORCE_VEC1", 0);
     c->opt[PGW_OPT_MULTIPASS] = env_flag("PGW_MULTIPASS", 1);
     c->opt[PGW_OPT_LOOP_GUESS] = 6;
+    c->opt[PGW_OPT_FORCE_OFF64] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&c->d_status, (2 + MULTI_MAX_PASS) * sizeof(DevStatus)) != hipSuccess ||
         hipHostMalloc(&c->h_status, (2 + 2 * MULTI_MAX_PASS) * sizeof(DevStatus)) != hipSuccess ||
@@ -775,7 +776,7 @@ static void launch_reinterp_pair(pgw_ctx *ctx, const Levels &lv, int ntime, int 
                                  const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, bool sfc, int check_top) {
     // 32-bit byte offsets when every array (fields: nlev levels, delta records: nplev levels) is smaller than 4 GiB
     const unsigned long long big = (unsigned long long)ntime * (lv.nlev > nplev ? lv.nlev : nplev) * ncol * sizeof(T);
-    if (big < (1ull << 32)) {
+    if (big < (1ull << 32) && !ctx->opt[PGW_OPT_FORCE_OFF64]) {
         if (sfc) launch_reinterp_pair_o<T, true, boff32>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
         else launch_reinterp_pair_o<T, false, boff32>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
     } else {
@@ -1325,7 +1326,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                     PairSrc<T> dwd{{(const T *)a->ua_b, exact ? nullptr : (const T *)a->ua_a, a->x_hi, a->x_new},
                                    {(const T *)a->va_b, exact ? nullptr : (const T *)a->va_a, a->x_hi, a->x_new}};
                     // arrays below 4 GiB (a 0.25 deg L137 field is 1.1 GB): 32-bit byte offsets from uniform bases
-                    const bool o32 = (unsigned long long)ntime * (N > S ? N : S) * ncol * sizeof(TL) < (1ull << 32);
+                    const bool o32 = !ctx->opt[PGW_OPT_FORCE_OFF64] &&
+                                     (unsigned long long)ntime * (N > S ? N : S) * ncol * sizeof(TL) < (1ull << 32);
                     // LERP: the instant lies between two records (false: it is a record, `exact`)
                     if (o32) { if (exact) LAUNCH_QUAD(boff32, false); else LAUNCH_QUAD(boff32, true); }
                     else { if (exact) LAUNCH_QUAD(boff64, false); else LAUNCH_QUAD(boff64, true); }

@@ -215,7 +215,7 @@ class Context:
         self._check(self.lib.pgw_sync(self.handle))
 
     def set_option(self, name, value):
-        """Per-context option of include/pgw_hip.h `enum pgw_option` ('quad', 'full_column', 'force_vec1', 'multipass', 'loop_guess');
+        """Per-context option of include/pgw_hip.h `enum pgw_option` ('quad', 'full_column', 'force_vec1', 'multipass', 'loop_guess', 'force_off64');
         returns the previous value."""
         old = self.get_option(name)
         self._check(self.lib.pgw_set_option(self.handle, _lib.OPTIONS[name], int(value)))

@@ -777,14 +777,17 @@ def test_reinterp_field_kernel_vs_oracle_composition(with_sfc):
     assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
 
 
+@pytest.mark.parametrize('off64', [0, 1])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
-def test_reinterp_pair_is_two_reinterp_fields_bit_for_bit(dtype):
+def test_reinterp_pair_is_two_reinterp_fields_bit_for_bit(dtype, off64, request):
     """pgw_reinterp_pair (ta + hur with the surface insertion, ua + va without) == two pgw_reinterp_field calls, bit for bit:
     surface pressures +-8 % apart, a time-interpolated instant and an exact record, a column with a NaN surface pressure
     (both scans restart) and ps_hist above / inside / at the edge of the delta levels."""
     import ctypes as C
     from pgw4era5_amd.device import default_context, dtype_tag
     ctx = default_context()
+    ctx.set_option('force_off64', off64)            # 1: the 64-bit byte-offset instantiation (arrays of 4 GiB and more)
+    request.addfinalizer(lambda: ctx.set_option('force_off64', 0))
     c = _case(7, 9, 23, seed=35, dtype=dtype)
     era, d = c['era'], c['deltas']
     ctx.set_levels(era['ak'], era['bk'])
@@ -833,6 +836,24 @@ def test_reinterp_pair_is_two_reinterp_fields_bit_for_bit(dtype):
                                              arr(D['a0'], D['a1']), 0.0, 0.0, None, None, None, None, arr(D['f0'], D['f1']), pe.ptr,
                                              pe.ptr, 0, arr(o0, o1)))
     assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
+
+
+def test_reference_dtype_mode_with_64_bit_offsets_is_bit_identical():
+    """float32 file, reference-dtype mode, through the 64-bit byte-offset instantiation of k_delta_quad."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    c = _case(8, 12, 27, seed=82, dtype=np.float32)
+    args = (c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    a = s3.pgw_for_era5_arrays(*args)
+    old = ctx.set_option('force_off64', 1)
+    try:
+        b = s3.pgw_for_era5_arrays(*args)
+    finally:
+        ctx.set_option('force_off64', old)
+    assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
+    for k in ['PS', 'T', 'QV', 'U', 'V']:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
 def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
@@ -1029,12 +1050,14 @@ def test_whole_file_errors_reach_python():
 
 @pytest.mark.parametrize('opts', [dict(quad=0), dict(full_column=1), dict(force_vec1=1), dict(multipass=0),
                                   dict(multipass=0, full_column=1), dict(quad=0, multipass=0, force_vec1=1),
-                                  dict(loop_guess=1), dict(loop_guess=2), dict(loop_guess=5), dict(loop_guess=8)])
+                                  dict(loop_guess=1), dict(loop_guess=2), dict(loop_guess=5), dict(loop_guess=8),
+                                  dict(force_off64=1)])
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_kernel_variants_are_bit_identical(opts, dtype):
     """Every selectable variant of the file path (pgw_set_option: pair kernels instead of the quad kernel, full-column
-    passes, scalar columns, one launch per loop pass instead of the column-resident multi-pass kernel) produces the
-    same bits as the default: they differ in scheduling, not in arithmetic."""
+    passes, scalar columns, one launch per loop pass instead of the column-resident multi-pass kernel, 64-bit byte offsets
+    - the instantiation arrays of 4 GiB and more take -) produces the same bits as the default: they differ in scheduling
+    and addressing, not in arithmetic."""
     from pgw4era5_amd import step_03_apply_to_era as s3
     from pgw4era5_amd.device import default_context
     ctx = default_context()
