@@ -2243,9 +2243,13 @@ __global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long l
     long long n = (long long)ntime * ncol;
     if (i >= n) return;
     long long t = i / ncol, c = i - t * ncol;
+    // REF and the instant IS a delta record (no time interpolation: the delta stays the file's float32, functions.py:282-283):
+    // numpy then takes `delta / 100`, the sum and the blend below in float32
+    const bool f32_delta = REF && !dsic.a;
     auto ice_of = [&](long long k) -> double {
         double s0 = (double)sic[k], d0 = dsic.template get<REF>(k);
         double v = s0 + d0 / 100;                                     // step_03:105
+        if (f32_delta) v = (double)((float)s0 + (float)d0 / 100.0f);
         v = fmin(fmax(v, 0.0), 1.0);                                  // :106-107
         if (s0 != s0 || d0 != d0) v = __builtin_nan("");              // np.clip keeps NaN
         return REF ? (double)(T)v : v;
@@ -2267,6 +2271,7 @@ __global__ __launch_bounds__(BLOCK) void k_surface_update_lerp(int ntime, long l
             omf = 1 - fr;
         }
         comb = fr * ts + omf * tos;                                   // :1184
+        if (f32_delta) comb = (double)((float)fr * (float)ts + (float)omf * (float)tos);   // float32 products and sum
     }
     tskin_out[i] = (T)((double)tskin[i] + comb);                      // step_03:124
     if (tso_out) {

@@ -6,6 +6,8 @@ relative (BASELINE.json north_star) - in practice the observed differences are ~
 contraction and libm-vs-ocml exp/log), so the tests assert 1e-9 where no cancellation occurs and
 the north_star 1e-6 on the end-to-end fields.  Index / branch decisions (which bracket, which
 level, iteration count) must be identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,8 @@ from oracle import pgw_oracle as O
 from oracle import pgw_oracle_refdtype as R
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RT = 1e-9
 
@@ -856,6 +860,40 @@ def test_reference_dtype_mode_with_64_bit_offsets_is_bit_identical():
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+def test_file_path_on_arrays_of_more_than_4_GiB():
+    """A 0.125 deg-sized file (4.17 M columns, L137, float64: 4.57 GB per 4-D field) takes the 64-bit byte-offset
+    instantiations and 64-bit index arithmetic for real.  Size-independent property: 16 copies of a 181 x 1440 file along
+    latitude give 16 copies of that file's result, bit for bit, with the same pass count and max|err| history
+    (tools/big_grid_check.py).  Needs ~90 GB of HBM and ~80 GB of host memory (skipped on a smaller machine)."""
+    import importlib.util
+    import psutil
+    from pgw4era5_amd.device import default_context
+    free, _ = default_context().mem_info()
+    if free < 120e9 or psutil.virtual_memory().available < 120e9:
+        pytest.skip('needs 120 GB of free HBM and of host memory')
+    spec = importlib.util.spec_from_file_location('big_grid_check', os.path.join(ROOT, 'tools', 'big_grid_check.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py: 400 small random files - grids down to one column, 8..44 levels, float32 (reference mode) and
+    float64, plev subsets, time stamps at records / across the year wrap, ps_hist above the delta levels, the fixed and the
+    local reference level, i_reinterp - HIP path against the oracles with this file's tolerances; no disagreement."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(ROOT, 'tools', 'fuzz_parity.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ['fuzz_parity.py', '--cases', '400', '--seed', '2']
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
+
+
 def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
     """it > max_n_iter raises even if that pass converged (step_03:313-319)."""
     from pgw4era5_amd import step_03_apply_to_era as s3
@@ -926,6 +964,11 @@ def test_reference_dtype_mode_exact_record_and_errors():
     for k in ('T', 'U', 'V'):
         np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-9, err_msg=k)
     assert _scaled_qv_diff(got['QV'], want['QV']) < 6e-7
+    # surface riders at a record: `delta / 100`, the sea-ice sum and the tos / ts blend are float32 operations in numpy
+    # (found by tools/fuzz_parity.py: float64 arithmetic is up to 26 float32 ulp away where sic + delta / 100 cancels)
+    np.testing.assert_array_equal(got['FR_SEA_ICE'], want['FR_SEA_ICE'])
+    for k in ('T_SKIN', 'T_SO'):
+        np.testing.assert_allclose(got[k], want[k], rtol=6e-8, atol=0, equal_nan=True, err_msg=k)
     with pytest.raises(ValueError) as e:
         s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], False)
     assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
