@@ -894,6 +894,23 @@ def test_randomised_parity_sweep():
         sys.argv = argv
 
 
+def test_randomised_function_level_sweep():
+    """tools/fuzz_functions.py: 600 random calls of the function-level entries (interp_logp_4d in its four modes against the
+    serial C column loops, vert_interp_delta, integ_geopot, humidity, regrid_field, smooth_annual_cycle) incl. their error
+    cases: values within the tolerances of this file, the same exception on both sides."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('fuzz_functions', os.path.join(ROOT, 'tools', 'fuzz_functions.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ['fuzz_functions.py', '--cases', '600', '--seed', '3']
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
+
+
 def test_loop_non_convergence_raises_the_reference_error(monkeypatch):
     """it > max_n_iter raises even if that pass converged (step_03:313-319)."""
     from pgw4era5_amd import step_03_apply_to_era as s3

@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the function-level entries (the `functions.py` mirror) against the oracles:
+interp_logp_4d in all four modes (against the serial C column loops, oracle/pgw_oracle_c.c: pinned by the reference's own
+vectors), vert_interp_delta with and without the surface insertion, integ_geopot with a scalar and a per-column p_ref,
+the humidity pair, regrid_field on random source / target grids (periodic or not, pole rows or not, target longitudes in
+-180..180 or 0..360), smooth_annual_cycle on random record counts.  Errors must agree as well.
+Test infrastructure (imports oracle/).  usage: python tools/fuzz_functions.py [--cases 400] [--seed 0]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from pgw4era5_amd import functions as F, synthetic
+from oracle import pgw_oracle as O, pgw_oracle_c as C
+
+
+def both(hip, ora):
+    """Run both sides; returns (got, want, note).  An exception on one side only is a failure."""
+    e1 = e2 = None
+    got = want = None
+    try:
+        got = hip()
+    except Exception as e:                      # noqa: BLE001
+        e1 = e
+    try:
+        want = ora()
+    except Exception as e:                      # noqa: BLE001
+        e2 = e
+    if e1 is None and e2 is None:
+        return got, want, None
+    if e1 is not None and e2 is not None:
+        # the oracle's messages are the first sentence of the reference's; the product carries the full text
+        if type(e1) is type(e2) and (str(e1) == str(e2) or not str(e2) or str(e1).startswith(str(e2).rstrip('.!'))):
+            return None, None, 'both raise'
+        return None, None, 'FAIL different errors: %s: %s / %s: %s' % (type(e1).__name__, e1, type(e2).__name__, e2)
+    return None, None, 'FAIL one side raises: HIP %r / oracle %r' % (e1, e2)
+
+
+def close(got, want, rtol, atol):
+    return bool(np.allclose(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), rtol=rtol, atol=atol, equal_nan=True))
+
+
+def case_interp(rng):
+    nt, S, N, nlat, nlon = int(rng.integers(1, 3)), int(rng.integers(2, 24)), int(rng.integers(1, 50)), int(rng.integers(1, 6)), int(rng.integers(1, 9))
+    sp = np.sort(rng.uniform(50., 1.05e5, (nt, S, nlat, nlon)), axis=1)
+    tp = np.sort(rng.uniform(20., 1.09e5, (nt, N, nlat, nlon)), axis=1)
+    var = rng.normal(size=(nt, S, nlat, nlon))
+    mode = str(rng.choice(['off', 'linear', 'constant', 'nan']))
+    r = rng.random()
+    if mode == 'off' and r < 0.8:
+        tp = np.clip(tp, sp[:, :1], sp[:, -1:])                              # in range: no error
+    if r < 0.3 and N > 1:
+        k = int(rng.integers(0, N)); s = int(rng.integers(0, S))
+        tp[:, k] = sp[:, s]                                                  # exact hits (may unsort a column: allowed inside)
+        if tp[0, -1, 0, 0] < tp[0, 0, 0, 0]:
+            tp = np.sort(tp, axis=1)
+    if rng.random() < 0.15:
+        var[0, int(rng.integers(0, S)), 0, 0] = np.nan
+    if rng.random() < 0.05:
+        sp[0, :, 0, 0] = sp[0, ::-1, 0, 0]                                   # descending source column -> ValueError
+    got, want, note = both(lambda: F.interp_logp_4d(var, sp, tp, mode), lambda: C.interp_logp_4d(var, sp, tp, mode))
+    if note:
+        return 'interp_' + mode, note
+    # the device logarithm is within 1 ulp of numpy's: 1e-13 of a slope of O(1e2) per unit ln p
+    return 'interp_' + mode, 'ok' if close(got, want, 1e-9, 1e-9) else 'FAIL values'
+
+
+def case_vert(rng):
+    nlat, nlon, N = int(rng.integers(1, 6)), int(rng.integers(1, 9)), int(rng.integers(2, 40))
+    keep = np.ones(19, dtype=bool)
+    if rng.random() < 0.5:
+        keep[rng.choice(np.arange(1, 18), size=int(rng.integers(1, 10)), replace=False)] = False
+    plev = synthetic.PLEV19[keep]
+    S = len(plev)
+    delta = rng.normal(size=(1, S, nlat, nlon))
+    tp = np.sort(rng.uniform(120., 1.06e5, (1, N, nlat, nlon)), axis=1)
+    with_sfc = rng.random() < 0.6
+    dsfc = rng.normal(size=(1, nlat, nlon)) if with_sfc else None
+    psh = rng.uniform(4.0e4, 1.06e5, (1, nlat, nlon)) if with_sfc else None
+    if with_sfc and rng.random() < 0.1:
+        psh[0, 0, 0] = 50.0                                                  # below the delta top -> ValueError()
+    ignore = rng.random() < 0.8
+    if rng.random() < 0.2:
+        tp[0, 0] = 30.0                                                      # above the delta top: error unless ignored
+        tp = np.sort(tp, axis=1)
+    got, want, note = both(lambda: F.vert_interp_delta(delta, tp, dsfc, psh, ignore, plev=plev),
+                           lambda: O.vert_interp_delta(delta, plev, tp, dsfc, psh, ignore))
+    if note:
+        return 'vert_interp_delta', note
+    return 'vert_interp_delta', 'ok' if close(got, want, 1e-9, 1e-9) else 'FAIL values'
+
+
+def case_geopot(rng):
+    c = synthetic.make_case(nlat=int(rng.integers(1, 7)), nlon=int(rng.integers(1, 9)), nlev=int(rng.integers(6, 40)),
+                            seed=int(rng.integers(0, 1 << 30)))
+    era = c['era']
+    pa_hl, _ = O.hybrid_pressure(era['ak'], era['bk'], era['PS'])
+    level1 = np.arange(1, len(era['ak']) + 1)
+    r = rng.random()
+    if r < 0.5:
+        p_ref = float(rng.choice([30000.0, 50000.0, 70000.0, 20000.0]))
+    elif r < 0.9:
+        p_ref = rng.uniform(1.0e4, 0.9 * era['PS'].min(), era['PS'].shape)
+    else:
+        p_ref = 2.0e5                                                        # below the surface -> ValueError
+    got, want, note = both(lambda: F.integ_geopot(pa_hl, era['FIS'], era['T'], era['QV'], level1, p_ref),
+                           lambda: O.integ_geopot(pa_hl, era['FIS'], era['T'], era['QV'], level1, p_ref))
+    if note:
+        return 'integ_geopot', note
+    return 'integ_geopot', 'ok' if close(got, want, 1e-11, 1e-6) else 'FAIL values'
+
+
+def case_humidity(rng):
+    shp = (1, int(rng.integers(1, 12)), int(rng.integers(1, 6)), int(rng.integers(1, 9)))
+    ta = rng.uniform(185.0, 320.0, shp)
+    ta.reshape(-1)[: min(3, ta.size)] = [273.16, 250.16, 260.0][: min(3, ta.size)]
+    pa = rng.uniform(1.0, 1.05e5, shp)
+    hus = 10.0 ** rng.uniform(-7, -1.7, shp)
+    got, want, note = both(lambda: F.specific_to_relative_humidity(hus, pa, ta), lambda: O.specific_to_relative_humidity(hus, pa, ta))
+    if note or not close(got, want, 1e-12, 0):
+        return 'humidity', note or 'FAIL q->rh'
+    hur = rng.uniform(-5.0, 120.0, shp)
+    got, want, note = both(lambda: F.relative_to_specific_humidity(hur, pa, ta), lambda: O.relative_to_specific_humidity(hur, pa, ta))
+    if note:
+        return 'humidity', note
+    return 'humidity', 'ok' if close(got, want, 1e-12, 1e-300) else 'FAIL rh->q'
+
+
+def case_regrid(rng):
+    nlat_s, nlon_s = int(rng.integers(4, 40)), int(rng.integers(6, 90))
+    nlat_t, nlon_t = int(rng.integers(2, 60)), int(rng.integers(2, 400))
+    periodic = rng.random() < 0.75
+    polar = rng.random() < 0.7
+    x = (np.arange(nlat_s) + 0.5) / nlat_s
+    src_lat = (-90.0 + 180.0 * x) * (1 - 0.3 / nlat_s)
+    if periodic:
+        src_lon = np.arange(nlon_s) * (360.0 / nlon_s)
+        targ_lon = np.arange(nlon_t) * (360.0 / nlon_t) - (180.0 if rng.random() < 0.5 else 0.0)
+    else:
+        src_lon = np.linspace(-30.0, 60.0, nlon_s)
+        targ_lon = np.linspace(-29.0 if rng.random() < 0.9 else -35.0, 58.0, nlon_t)    # -35: outside -> ValueError
+    if polar:
+        targ_lat = np.linspace(-90.0, 90.0, nlat_t)
+    else:
+        targ_lat = np.linspace(src_lat[0] + 0.1, src_lat[-1] - 0.1, nlat_t)
+    if rng.random() < 0.2:
+        targ_lat = targ_lat[::-1].copy()
+    f = rng.normal(size=(int(rng.integers(1, 4)), int(rng.integers(1, 4)), nlat_s, nlon_s))
+    if rng.random() < 0.3:
+        f[0, 0, int(rng.integers(0, nlat_s)), int(rng.integers(0, nlon_s))] = np.nan
+    got, want, note = both(lambda: F.regrid_field(f, src_lat, src_lon, targ_lat, targ_lon),
+                           lambda: O.regrid_lat_lon(f, src_lat, src_lon, targ_lat, targ_lon))
+    if note:
+        return 'regrid', note
+    return 'regrid', 'ok' if close(got, want, 1e-12, 1e-13) else 'FAIL values'
+
+
+def case_smooth(rng):
+    nt = int(rng.choice([8, 9, 12, 360, 365, 366, int(rng.integers(7, 400))]))
+    x = rng.normal(size=(nt, int(rng.integers(1, 4)), int(rng.integers(1, 5)), int(rng.integers(1, 7))))
+    if rng.random() < 0.3:
+        x[int(rng.integers(0, nt)), 0, 0, 0] = np.nan
+    got, want, note = both(lambda: F.smooth_annual_cycle(x), lambda: O.filter_data_array(x))
+    if note:
+        return 'smooth', note
+    return 'smooth', 'ok' if close(got, want, 1e-11, 1e-12) else 'FAIL values'
+
+
+CASES = [case_interp, case_interp, case_vert, case_vert, case_geopot, case_humidity, case_regrid, case_regrid, case_smooth]
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('--cases', type=int, default=400)
+    p.add_argument('--seed', type=int, default=0)
+    a = p.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    counts, fails = {}, []
+    for i in range(a.cases):
+        fn = CASES[int(rng.integers(0, len(CASES)))]
+        state = rng.bit_generator.state
+        name, res = fn(rng)
+        key = res if res in ('ok', 'both raise') else 'FAIL'
+        counts[name + ':' + key] = counts.get(name + ':' + key, 0) + 1
+        if key == 'FAIL':
+            fails.append(dict(i=i, case=name, result=res[:300]))
+            print(json.dumps(fails[-1]), flush=True)
+        del state
+    print(json.dumps(dict(cases=a.cases, seed=a.seed, seconds=round(time.time() - t0, 1), counts=dict(sorted(counts.items())),
+                         failures=fails[:20])))
+    return 1 if fails else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
