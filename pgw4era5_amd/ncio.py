@@ -558,7 +558,7 @@ def to_netcdf(ds, path, threads=None):
         if data.dtype == np.bool_:
             data = data.astype(np.int8)
         key = data.dtype.str[1:]
-        if key not in _NC_TYPE or key == 'S1':
+        if key not in _NC_TYPE:             # 'S1': NC_CHAR variables (e.g. the scalar `char rotated_pole` grid-mapping carrier)
             raise TypeError('variable %s: dtype %s cannot be stored in NetCDF-3' % (name, data.dtype))
         record = record_dim is not None and len(f.dims) > 0 and f.dims[0] == record_dim
         nbytes = int(data.size) * data.dtype.itemsize

@@ -284,8 +284,13 @@ def write_case_files(case, era_dir, delta_dir, era_name=None):
     ds['bk'] = F(era['bk'], ('level1',), {'level1': cv['level1']})
     d4 = ('time', 'level', 'lat', 'lon')
     d3 = ('time', 'lat', 'lon')
+    # a scalar NC_CHAR variable that only carries attributes, as in COSMO / int2lm boundary files (`char rotated_pole`):
+    # the driver has to pass it through untouched
+    ds['rotated_pole'] = F(np.array(b'', dtype='S1'), (), attrs=dict(grid_mapping_name='rotated_latitude_longitude',
+                                                                     grid_north_pole_latitude=np.float32(43.0),
+                                                                     grid_north_pole_longitude=np.float32(-170.0)))
     for name in ('T', 'QV', 'U', 'V'):
-        ds[name] = F(era[name], d4, {d: cv[d] for d in d4})
+        ds[name] = F(era[name], d4, {d: cv[d] for d in d4}, attrs=dict(grid_mapping='rotated_pole'))
     for name in ('PS', 'FIS', 'T_SKIN', 'FR_LAND', 'FR_SEA_ICE'):
         ds[name] = F(era[name], d3, {d: cv[d] for d in d3})
     ds['T_SO'] = F(era['T_SO'], ('time', 'soil1', 'lat', 'lon'), {d: cv[d] for d in ('time', 'soil1', 'lat', 'lon')})

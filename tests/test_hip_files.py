@@ -55,6 +55,11 @@ def test_step03_cli_end_to_end(files):
         assert ds['QV'].values.dtype == np.float64 and np.nanmax(np.abs(ds['QV'].values - want['QV']) / scale) < 6e-7
         np.testing.assert_array_equal(ds['FIS'].values, c['era']['FIS'])      # untouched variables pass through
         np.testing.assert_array_equal(ds['ak'].values, c['era']['ak'])
+        # the attribute-only scalar char variable of COSMO-style files survives, and T still points at it
+        assert ds['rotated_pole'].values.dtype == np.dtype('S1') and ds['rotated_pole'].dims == ()
+        assert ds['rotated_pole'].attrs['grid_mapping_name'] == 'rotated_latitude_longitude'
+        assert ds['rotated_pole'].attrs['grid_north_pole_latitude'] == np.float32(43.0)
+        assert ds['T'].attrs['grid_mapping'] == 'rotated_pole'
 
 
 def test_step03_fill_value_encoded_deltas(tmp_path):

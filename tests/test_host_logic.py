@@ -162,6 +162,16 @@ def test_writer_variants_produce_the_same_data(tmp_path, monkeypatch):
     assert a['a'].attrs['units'] == b['a'].attrs['units'] == 'K'
 
 
+def test_ncio_random_files_against_scipy():
+    """tools/fuzz_ncio.py: random classic / 64-bit-offset files (record and fixed variables of every classic type incl.
+    NC_CHAR, scalars, attributes) written by scipy -> native reader -> native writer -> scipy: nothing is lost."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('fuzz_ncio', os.path.join(ROOT, 'tools', 'fuzz_ncio.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(seed=4, cases=120) == 0
+
+
 def test_decode_cf_time_calendars():
     from pgw4era5_amd.ncio import decode_cf_time
     got = decode_cf_time([0, 31, 59.5], 'days since 1850-01-01 00:00:00', 'proleptic_gregorian')
