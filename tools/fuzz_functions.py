@@ -170,7 +170,31 @@ def case_smooth(rng):
     return 'smooth', 'ok' if close(got, want, 1e-11, 1e-12) else 'FAIL values'
 
 
-CASES = [case_interp, case_interp, case_vert, case_vert, case_geopot, case_humidity, case_regrid, case_regrid, case_smooth]
+def case_ocean(rng):
+    """NaN-ignoring Gaussian-kernel interpolation from a curvilinear ocean grid (functions.py:900-1060; parity unpinned:
+    the oracle restates the published VTK / Vincenty formulas) on small random grids, radii and sharpness values."""
+    oc = synthetic.make_ocean_grid_case(nj=int(rng.integers(8, 22)), ni=int(rng.integers(10, 30)), ntime=int(rng.integers(1, 4)),
+                                        seed=int(rng.integers(0, 1 << 30)), land_patches=int(rng.integers(0, 4)))
+    nlat, nlon = int(rng.integers(5, 14)), int(rng.integers(6, 21))
+    lat = np.linspace(-90.0, 90.0, nlat)
+    lon = np.arange(nlon) * (360.0 / nlon)
+    land = (rng.uniform(size=(nlat, nlon)) > 0.8).astype(np.float64)
+    R, sh = float(rng.uniform(0.8e6, 4.0e6)), float(rng.choice([1.0, 3.0, 4.0]))
+    got = F.gauss_interp_fields(land, lat, lon, oc['latitude'], oc['longitude'], list(oc['values']), R, sh)
+    for m in range(len(oc['values'])):
+        try:
+            want = O.nan_ignoring_interp(land, lat, lon, oc['latitude'], oc['longitude'], oc['values'][m], R, sh)
+        except ValueError as e:
+            if 'outside this oracle' in str(e):          # Vincenty's inverse iteration near antipodal points
+                return 'ocean', 'both raise'
+            raise
+        if not close(got[m], want, 1e-9, 0):
+            return 'ocean', 'FAIL values (month %d)' % m
+    return 'ocean', 'ok'
+
+
+CASES = [case_interp, case_interp, case_vert, case_vert, case_geopot, case_humidity, case_regrid, case_regrid, case_smooth,
+         case_ocean]
 
 
 def main():
