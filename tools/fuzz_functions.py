@@ -62,11 +62,16 @@ def case_interp(rng):
         var[0, int(rng.integers(0, S)), 0, 0] = np.nan
     if rng.random() < 0.05:
         sp[0, :, 0, 0] = sp[0, ::-1, 0, 0]                                   # descending source column -> ValueError
+    f32 = rng.random() < 0.3                                                 # float32 storage: float64 arithmetic on the stored values
+    if f32:
+        var, sp, tp = var.astype(np.float32), sp.astype(np.float32), tp.astype(np.float32)
     got, want, note = both(lambda: F.interp_logp_4d(var, sp, tp, mode), lambda: C.interp_logp_4d(var, sp, tp, mode))
     if note:
         return 'interp_' + mode, note
+    if f32 and got.dtype != np.float32:
+        return 'interp_' + mode, 'FAIL dtype %s' % got.dtype
     # the device logarithm is within 1 ulp of numpy's: 1e-13 of a slope of O(1e2) per unit ln p
-    return 'interp_' + mode, 'ok' if close(got, want, 1e-9, 1e-9) else 'FAIL values'
+    return 'interp_' + mode, 'ok' if close(got, want, *((2e-6, 2e-6) if f32 else (1e-9, 1e-9))) else 'FAIL values'
 
 
 def case_vert(rng):
@@ -87,11 +92,16 @@ def case_vert(rng):
     if rng.random() < 0.2:
         tp[0, 0] = 30.0                                                      # above the delta top: error unless ignored
         tp = np.sort(tp, axis=1)
+    f32 = rng.random() < 0.3
+    if f32:
+        delta, tp = delta.astype(np.float32), tp.astype(np.float32)
+        if with_sfc:
+            dsfc, psh = dsfc.astype(np.float32), psh.astype(np.float32)
     got, want, note = both(lambda: F.vert_interp_delta(delta, tp, dsfc, psh, ignore, plev=plev),
                            lambda: O.vert_interp_delta(delta, plev, tp, dsfc, psh, ignore))
     if note:
         return 'vert_interp_delta', note
-    return 'vert_interp_delta', 'ok' if close(got, want, 1e-9, 1e-9) else 'FAIL values'
+    return 'vert_interp_delta', 'ok' if close(got, want, *((2e-6, 2e-6) if f32 else (1e-9, 1e-9))) else 'FAIL values'
 
 
 def case_geopot(rng):
@@ -152,11 +162,14 @@ def case_regrid(rng):
     f = rng.normal(size=(int(rng.integers(1, 4)), int(rng.integers(1, 4)), nlat_s, nlon_s))
     if rng.random() < 0.3:
         f[0, 0, int(rng.integers(0, nlat_s)), int(rng.integers(0, nlon_s))] = np.nan
+    f32 = rng.random() < 0.3
+    if f32:
+        f = f.astype(np.float32)
     got, want, note = both(lambda: F.regrid_field(f, src_lat, src_lon, targ_lat, targ_lon),
-                           lambda: O.regrid_lat_lon(f, src_lat, src_lon, targ_lat, targ_lon))
+                           lambda: O.regrid_lat_lon(f.astype(np.float64), src_lat, src_lon, targ_lat, targ_lon))
     if note:
         return 'regrid', note
-    return 'regrid', 'ok' if close(got, want, 1e-12, 1e-13) else 'FAIL values'
+    return 'regrid', 'ok' if close(got, want, *((1e-6, 1e-6) if f32 else (1e-12, 1e-13))) else 'FAIL values'
 
 
 def case_smooth(rng):
