@@ -230,6 +230,19 @@ int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long n
                       const void *const *dsfc_b, const void *const *dsfc_a, const void *pshist_b, const void *pshist_a,
                       const void *const *era_field, const void *ps_era, const void *ps_pgw, int ignore_top, void *const *out);
 
+/* f3  one pass of the surface-pressure loop with settings.i_reinterp = 1 (step_03_apply_to_era.py:192-216, 262-308) in one
+ * call and one host synchronisation: delta_ps += adj_ps, ps_pgw = PS + delta_ps (:192-193); ta_pgw / hur_pgw =
+ * interp_logp_4d(T / RELHUM of the ERA state, pa_era, pa_pgw, 'constant') + load_delta_interp(ta / hur, pa_pgw) (:202-216,
+ * pgw_reinterp_pair, which also leaves e = hur_pgw / 100 * e_sat(ta_pgw) in a workspace); then the pass of pgw_adjust_ps_step
+ * on them: adj_ps and the global max |phi error| (:262-308).  Same bits as pgw_update_ps + pgw_reinterp_pair +
+ * pgw_adjust_ps_step(apply_adj = 0).  ps_pgw (ntime, ncol), ta_pgw, hur_pgw (ntime, nlev, ncol) are outputs. */
+int pgw_reinterp_pass(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol, const double *plev,
+                      const void *const *delta_b, const void *const *delta_a, double x_hi, double x_new,
+                      const void *const *dsfc_b, const void *const *dsfc_a, const void *pshist_b, const void *pshist_a,
+                      const void *T_era, const void *RELHUM_era, const void *PS, const void *FIS, const double *phi_ref_era,
+                      const double *dphi_clim, double *delta_ps, double *adj_ps, double p_ref, double adj_factor,
+                      int ignore_top, void *ps_pgw, void *ta_pgw, void *hur_pgw, double *max_abs_err);
+
 /* replace_delta_sfc(source_P, ps_hist, delta, delta_sfc)  functions.py:343-366, on many columns:
  * plev_asc (nplev, host, ascending); delta (ntime, nplev, ncol) in ascending order;
  * delta_sfc, ps_hist (ntime, ncol); outputs out_P, out_delta (ntime, nplev, ncol). */

@@ -82,6 +82,8 @@ SIGNATURES = {
                                    _vp, _vp, _i, _vp, _vp]),
     'pgw_reinterp_field': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'pgw_reinterp_pair': (_i, [_vp, _i, _i, _i, _ll, _dp, _vpp, _vpp, _d, _d, _vpp, _vpp, _vp, _vp, _vpp, _vp, _vp, _i, _vpp]),
+    'pgw_reinterp_pass': (_i, [_vp, _i, _i, _i, _ll, _dp, _vpp, _vpp, _d, _d, _vpp, _vpp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _d, _d, _i, _vp, _vp, _vp, _dp]),
     'pgw_replace_delta_sfc': (_i, [_vp, _i, _i, _i, _ll, _dp, _vp, _vp, _vp, _vp, _vp]),
     'pgw_integrate_tos': (_i, [_vp, _i, _ll, _vp, _vp, _vp, _vp, _vp]),
     'pgw_adjust_ps_step': (_i, [_vp, _i, _i, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _d, _i, _dp]),

@@ -764,10 +764,10 @@ extern "C" int pgw_reinterp_field(pgw_ctx *ctx, int dtype, int ntime, int nplev,
     return PGW_OK;
 }
 
-template <typename T, bool SFC, typename O>
+template <typename T, bool SFC, typename O, bool EVAP>
 static void launch_reinterp_pair_o(pgw_ctx *ctx, const Levels &lv, int ntime, long long ncol, const ReinterpPair<T> &rv,
                                    const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, int check_top) {
-    hipLaunchKernelGGL((k_reinterp_pair<T, SFC, O>), dim3(nblocks((long long)ntime * ncol, BLOCK)), dim3(BLOCK),
+    hipLaunchKernelGGL((k_reinterp_pair<T, SFC, O, EVAP>), dim3(nblocks((long long)ntime * ncol, BLOCK)), dim3(BLOCK),
                        2 * lv.nlev * sizeof(double), ctx->stream, ctx->plev_tab, lv, ntime, ncol, rv, p, ps_era, ps_pgw,
                        check_top, ctx->d_status);
 }
@@ -776,12 +776,16 @@ static void launch_reinterp_pair(pgw_ctx *ctx, const Levels &lv, int ntime, int 
                                  const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, bool sfc, int check_top) {
     // 32-bit byte offsets when every array (fields: nlev levels, delta records: nplev levels) is smaller than 4 GiB
     const unsigned long long big = (unsigned long long)ntime * (lv.nlev > nplev ? lv.nlev : nplev) * ncol * sizeof(T);
-    if (big < (1ull << 32) && !ctx->opt[PGW_OPT_FORCE_OFF64]) {
-        if (sfc) launch_reinterp_pair_o<T, true, boff32>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-        else launch_reinterp_pair_o<T, false, boff32>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+    const bool o32 = big < (1ull << 32) && !ctx->opt[PGW_OPT_FORCE_OFF64];
+    if (rv.evap) {                                       // the loop's ta + hur pair (always with the surface insertion)
+        if (o32) launch_reinterp_pair_o<T, true, boff32, true>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, true, boff64, true>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+    } else if (o32) {
+        if (sfc) launch_reinterp_pair_o<T, true, boff32, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, false, boff32, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
     } else {
-        if (sfc) launch_reinterp_pair_o<T, true, boff64>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-        else launch_reinterp_pair_o<T, false, boff64>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        if (sfc) launch_reinterp_pair_o<T, true, boff64, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, false, boff64, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
     }
 }
 
@@ -815,6 +819,7 @@ extern "C" int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, 
                 rv.era[v] = (const T *)era_field[v];
                 rv.out[v] = (T *)out[v];
             }
+            rv.evap = nullptr;
             DeltaSrc<T> p{(const T *)pshist_b, lerp ? (const T *)pshist_a : nullptr, x_hi, x_new};
             launch_reinterp_pair<T>(ctx, lv, ntime, nplev, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, dsfc_b != nullptr,
                                     ignore_top ? 0 : 1);
@@ -933,6 +938,68 @@ extern "C" int pgw_adjust_ps_step(pgw_ctx *ctx, int dtype, int ntime, long long 
     rc = status_check(ctx);
     if (max_abs_err) *max_abs_err = max_err_of(ctx);
     return rc;
+}
+
+extern "C" int pgw_reinterp_pass(pgw_ctx *ctx, int dtype, int ntime, int nplev, long long ncol, const double *plev,
+                                 const void *const *delta_b, const void *const *delta_a, double x_hi, double x_new,
+                                 const void *const *dsfc_b, const void *const *dsfc_a, const void *pshist_b,
+                                 const void *pshist_a, const void *T_era, const void *RELHUM_era, const void *PS,
+                                 const void *FIS, const double *phi_ref_era, const double *dphi_clim, double *delta_ps,
+                                 double *adj_ps, double p_ref, double adj_factor, int ignore_top, void *ps_pgw,
+                                 void *ta_pgw, void *hur_pgw, double *max_abs_err) {
+    CHECK_COMMON(ctx, dtype, ntime, ncol);
+    NEED(ctx, nplev >= 2 && nplev <= MAX_PLEV, "nplev must be in [2, 64]");
+    NEED(ctx, ctx->nlev > 0, "pgw_set_levels has not been called");
+    NEED(ctx, plev && delta_b && dsfc_b && pshist_b && T_era && RELHUM_era && PS && FIS && phi_ref_era && dphi_clim && delta_ps &&
+         adj_ps && ps_pgw && ta_pgw && hur_pgw, "null pointer");
+    NEED(ctx, delta_b[0] && delta_b[1] && dsfc_b[0] && dsfc_b[1], "null pointer");
+    const bool lerp = (x_hi != 0.0);
+    NEED(ctx, !lerp || (delta_a && delta_a[0] && delta_a[1] && dsfc_a && dsfc_a[0] && dsfc_a[1] && pshist_a),
+         "the record after the instant is missing");
+    const size_t es = dtype == PGW_F64 ? 8 : 4;
+    void *evap = nullptr;
+    int rc = ws_get(ctx, 0, (size_t)ntime * ctx->nlev * ncol * es, &evap);
+    if (rc) return rc;
+    if ((rc = plev_table(ctx, nplev, plev))) return rc;
+    if ((rc = status_reset(ctx))) return rc;
+    Levels lv = levels_of(ctx);
+    const long long n2 = (long long)ntime * ncol;
+    {   // step_03:192-193
+        DISPATCH_T(dtype, hipLaunchKernelGGL((k_update_ps<T>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2,
+                                             (const T *)PS, delta_ps, adj_ps, (T *)ps_pgw));
+    }
+    {   // :202-216 for ta and hur, + e of functions.py:123
+        Prof pr(ctx, PGW_K_VERT_INTERP_DELTA);
+        DISPATCH_T(dtype, {
+            ReinterpPair<T> rv;
+            for (int v = 0; v < 2; ++v) {
+                rv.d[v] = DeltaSrc<T>{(const T *)delta_b[v], lerp ? (const T *)delta_a[v] : nullptr, x_hi, x_new};
+                rv.sfc[v] = DeltaSrc<T>{(const T *)dsfc_b[v], lerp ? (const T *)dsfc_a[v] : nullptr, x_hi, x_new};
+            }
+            rv.era[0] = (const T *)T_era; rv.era[1] = (const T *)RELHUM_era;
+            rv.out[0] = (T *)ta_pgw; rv.out[1] = (T *)hur_pgw;
+            rv.evap = (T *)evap;
+            DeltaSrc<T> p{(const T *)pshist_b, lerp ? (const T *)pshist_a : nullptr, x_hi, x_new};
+            launch_reinterp_pair<T>(ctx, lv, ntime, nplev, ncol, rv, p, (const T *)PS, (const T *)ps_pgw, true, ignore_top ? 0 : 1);
+        });
+    }
+    // :262-308: the pass on the re-interpolated fields (delta_ps already carries this pass's increment)
+    launch_step(ctx, dtype, ntime, ncol, ta_pgw, evap, PS, FIS, phi_ref_era, dphi_clim, delta_ps, adj_ps, p_ref, nullptr,
+                adj_factor, ctx->opt[PGW_OPT_FULL_COLUMN], 0);
+    HIPCHK(ctx, hipGetLastError());
+    rc = status_check(ctx);
+    if (max_abs_err) *max_abs_err = max_err_of(ctx);
+    if (rc) return rc;
+    if (!ignore_top) {                                     // functions.py:417-425
+        DevStatus *h = ctx->h_status;
+        if (!h->nan_seen && h->min_targ_bits != ~0ull && h->min_src_bits != ~0ull) {
+            double mt, ms;
+            memcpy(&mt, &h->min_targ_bits, 8);
+            memcpy(&ms, &h->min_src_bits, 8);
+            if (mt < ms) { ctx->err = status_text(PGW_ERR_TOP_PRESSURE); ctx->err_col = -1; return PGW_ERR_TOP_PRESSURE; }
+        }
+    }
+    return PGW_OK;
 }
 
 extern "C" int pgw_update_ps(pgw_ctx *ctx, int dtype, long long n, const void *PS, double *delta_ps,

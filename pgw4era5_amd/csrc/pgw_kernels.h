@@ -1012,15 +1012,22 @@ struct ReinterpPair {
     DeltaSrc<T> d[2], sfc[2];
     const T *era[2];
     T *out[2];
+    T *evap;               // EVAP: the vapour pressure of (out[1], out[0]) = (hur_pgw, ta_pgw), what the loop pass reads
 };
 constexpr int RING = 8, RING_LEAD = 4;
 
+#ifndef RP_MINW_EVAP
+#define RP_MINW_EVAP 3     // with the e_sat chain 128 VGPRs spill 116 bytes into the level loop (scratch reloads are vector loads: they drain the row prefetch)
+#endif
 #ifndef RP_MINW
 #define RP_MINW 4
 #endif
 // O: byte-offset type of ld_off / st_off (32-bit when every array is smaller than 4 GiB)
-template <typename T, bool HAS_SFC, typename O>
-__global__ __launch_bounds__(BLOCK, RP_MINW) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol, ReinterpPair<T> rv,
+// EVAP (ta + hur inside the loop): also writes e = hur_pgw / 100 * e_sat(ta_pgw) (functions.py:123) of the STORED values,
+// the iterate-independent half of relative_to_specific_humidity that k_adjust_ps_step reads - the bits of a separate
+// k_humidity_hybrid<.., 2> pass over the two outputs, without reading them back
+template <typename T, bool HAS_SFC, typename O, bool EVAP = false>
+__global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol, ReinterpPair<T> rv,
                                                             DeltaSrc<T> psh, const T *__restrict__ ps_era,
                                                             const T *__restrict__ ps_pgw, int check_top, DevStatus *st) {
     extern __shared__ double lds_rp[];               // akm[N] | bkm[N]
@@ -1181,8 +1188,10 @@ __global__ __launch_bounds__(BLOCK, RP_MINW) void k_reinterp_pair(PlevTable pt, 
                         y1 = b_lo + by_D.divide(dx * (b_hi - b_lo));
                     }
                     const O o = obase + (O)l * row;
-                    st_off_nt(rv.out[0], o, (T)(e0 + y0));                                      // vars_era + deltas  :216
-                    st_off_nt(rv.out[1], o, (T)(e1 + y1));
+                    const T r0 = (T)(e0 + y0), r1 = (T)(e1 + y1);                               // vars_era + deltas  :216
+                    st_off_nt(rv.out[0], o, r0);
+                    st_off_nt(rv.out[1], o, r1);
+                    if (EVAP) st_off(rv.evap, o, (T)rh_to_e((double)r1, (double)r0));
                     xprev = (x == x) ? x : __builtin_inf();
                 }
             }

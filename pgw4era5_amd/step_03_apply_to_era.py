@@ -304,12 +304,18 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     it = 1
     hist = []
     max_err = C.c_double()
+    def arr(*xs):
+        return (C.c_void_p * 2)(*[x.ptr for x in xs])
+    thermo = (arr(dev['ta'].slab(rb), dev['hur'].slab(rb)), arr(dev['ta'].slab(ra), dev['hur'].slab(ra)), x_hi, x_new,
+              arr(dev['tas'].slab(rb), dev['hurs'].slab(rb)), arr(dev['tas'].slab(ra), dev['hurs'].slab(ra)),
+              dev['ps_hist'].slab(rb).ptr, dev['ps_hist'].slab(ra).ptr)
     while err > S.thresh_phi_ref_max_error:                                       # :189
-        ctx._check(lib.pgw_update_ps(h, tag, n2, PS.ptr, delta_ps.ptr, adj_ps.ptr, ps_pgw.ptr))   # :192-193
-        reinterp_pair('ta', 'hur', T, relhum, ta_pgw, hur_pgw)
-        ctx._check(lib.pgw_adjust_ps_step(h, tag, nt, ncol, ta_pgw.ptr, hur_pgw.ptr, PS.ptr, FIS.ptr, phi_era.ptr,
-                                          dphi.ptr, delta_ps.ptr, adj_ps.ptr, float(p_ref), None, float(S.adj_factor), 0,
-                                          C.byref(max_err)))
+        # one call and one host round trip per pass: delta_ps += adj_ps, ps_pgw (:192-193); ta / hur re-interpolated onto
+        # the new levels (:202-216); the pass on them (:262-308)
+        ctx._check(lib.pgw_reinterp_pass(h, tag, nt, len(plev), ncol, plev.ctypes.data_as(_dp), *thermo, T.ptr, relhum.ptr,
+                                         PS.ptr, FIS.ptr, phi_era.ptr, dphi.ptr, delta_ps.ptr, adj_ps.ptr, float(p_ref),
+                                         float(S.adj_factor), 1 if ignore_top_pressure_error else 0, ps_pgw.ptr, ta_pgw.ptr,
+                                         hur_pgw.ptr, C.byref(max_err)))
         err = max_err.value                                                       # :308
         hist.append(err)
         it += 1

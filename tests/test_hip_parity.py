@@ -842,6 +842,61 @@ def test_reinterp_pair_is_two_reinterp_fields_bit_for_bit(dtype, off64, request)
     assert 'ERA5 top pressure is lower than climate delta top pressure' in str(e.value)
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_reinterp_pass_is_its_three_steps_bit_for_bit(dtype):
+    """pgw_reinterp_pass (one call per loop pass of i_reinterp = 1) == pgw_update_ps + pgw_reinterp_pair(ta, hur) +
+    pgw_adjust_ps_step(apply_adj = 0): ps_pgw, ta_pgw, hur_pgw, delta_ps, adj_ps and max |err| over two passes."""
+    import ctypes as C
+    from pgw4era5_amd.device import default_context, dtype_tag
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    ctx = default_context()
+    c = _case(7, 9, 23, seed=37, dtype=dtype)
+    era, d = c['era'], c['deltas']
+    ctx.set_levels(era['ak'], era['bk'])
+    nt, N, nlat, nlon = era['T'].shape
+    ncol, tag = nlat * nlon, dtype_tag(np.dtype(dtype))
+    plev = np.ascontiguousarray(c['plev'], dtype=np.float64)
+    dp = C.POINTER(C.c_double)
+    up = lambda v, t=dtype: ctx.to_device(np.ascontiguousarray(v, dtype=t))
+    rb, ra, x_hi, x_new = 3, 4, 31.0, 11.5
+    D = {k: up(v) for k, v in dict(T=era['T'], RH=O.specific_to_relative_humidity(era['QV'].astype(np.float64),
+                                                                                   O.hybrid_pressure(era['ak'], era['bk'], era['PS'].astype(np.float64))[1],
+                                                                                   era['T'].astype(np.float64)),
+                                   PS=era['PS'], FIS=era['FIS'], tb=d['ta'][rb], ta=d['ta'][ra], hb=d['hur'][rb], ha=d['hur'][ra],
+                                   tsb=d['tas'][rb], tsa=d['tas'][ra], hsb=d['hurs'][rb], hsa=d['hurs'][ra],
+                                   pb=d['ps_hist'][rb], pa=d['ps_hist'][ra]).items()}
+    rng = np.random.default_rng(3)
+    phi_era = up(rng.normal(5.0e4, 10.0, era['PS'].shape), np.float64)
+    dphi = up(rng.normal(300.0, 30.0, era['PS'].shape), np.float64)
+    arr = lambda a, b: (C.c_void_p * 2)(a.ptr, b.ptr)
+    res = []
+    for fused in (False, True):
+        dps, adj = up(np.zeros(era['PS'].shape), np.float64), up(rng.normal(0.0, 0.0, era['PS'].shape) + 25.0, np.float64)
+        ps, ta, hur = ctx.empty(era['PS'].shape, dtype), ctx.empty(era['T'].shape, dtype), ctx.empty(era['T'].shape, dtype)
+        errs = []
+        for _ in range(2):
+            me = C.c_double()
+            if fused:
+                ctx._check(ctx.lib.pgw_reinterp_pass(ctx.handle, tag, nt, len(plev), ncol, plev.ctypes.data_as(dp), arr(D['tb'], D['hb']),
+                                                     arr(D['ta'], D['ha']), x_hi, x_new, arr(D['tsb'], D['hsb']), arr(D['tsa'], D['hsa']),
+                                                     D['pb'].ptr, D['pa'].ptr, D['T'].ptr, D['RH'].ptr, D['PS'].ptr, D['FIS'].ptr,
+                                                     phi_era.ptr, dphi.ptr, dps.ptr, adj.ptr, 30000.0, 0.95, 1, ps.ptr, ta.ptr, hur.ptr,
+                                                     C.byref(me)))
+            else:
+                ctx._check(ctx.lib.pgw_update_ps(ctx.handle, tag, nt * ncol, D['PS'].ptr, dps.ptr, adj.ptr, ps.ptr))
+                ctx._check(ctx.lib.pgw_reinterp_pair(ctx.handle, tag, nt, len(plev), ncol, plev.ctypes.data_as(dp), arr(D['tb'], D['hb']),
+                                                     arr(D['ta'], D['ha']), x_hi, x_new, arr(D['tsb'], D['hsb']), arr(D['tsa'], D['hsa']),
+                                                     D['pb'].ptr, D['pa'].ptr, arr(D['T'], D['RH']), D['PS'].ptr, ps.ptr, 1, arr(ta, hur)))
+                ctx._check(ctx.lib.pgw_adjust_ps_step(ctx.handle, tag, nt, ncol, ta.ptr, hur.ptr, D['PS'].ptr, D['FIS'].ptr, phi_era.ptr,
+                                                      dphi.ptr, dps.ptr, adj.ptr, 30000.0, None, 0.95, 0, C.byref(me)))
+            errs.append(me.value)
+        res.append(dict(ps=ps.numpy(), ta=ta.numpy(), hur=hur.numpy(), dps=dps.numpy(), adj=adj.numpy(), errs=errs))
+    a, b = res
+    assert a['errs'] == b['errs'] and np.isfinite(a['errs']).all() and a['errs'][0] != a['errs'][1]
+    for k in ('ps', 'ta', 'hur', 'dps', 'adj'):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_reference_dtype_mode_with_64_bit_offsets_is_bit_identical():
     """float32 file, reference-dtype mode, through the 64-bit byte-offset instantiation of k_delta_quad."""
     from pgw4era5_amd import step_03_apply_to_era as s3
