@@ -488,3 +488,19 @@ def test_a_band_that_fails_fails_all_bands(tmp_path, mode):
             assert msgs[r].startswith('ValueError: p_ref locally lies below the surface'), msgs
         else:
             assert msgs[r] == 'ValueError: ', msgs
+
+
+def test_randomised_file_layout_sweep():
+    """tools/fuzz_files.py: the step_03 command line over 80 random ERA5 file layouts (float32 / float64, unlimited or fixed
+    `time`, shuffled variables, pass-through extras incl. integer and char variables, akm / bkm in the file, a transposed
+    4-D field, raw or converted host I/O): written fields against the oracles, everything else byte for byte."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('fuzz_files', os.path.join(ROOT, 'tools', 'fuzz_files.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ['fuzz_files.py', '--cases', '80', '--seed', '4']
+    try:
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
