@@ -162,6 +162,9 @@ def case_regrid(rng):
     f = rng.normal(size=(int(rng.integers(1, 4)), int(rng.integers(1, 4)), nlat_s, nlon_s))
     if rng.random() < 0.3:
         f[0, 0, int(rng.integers(0, nlat_s)), int(rng.integers(0, nlon_s))] = np.nan
+    if rng.random() < 0.25:                        # GCM latitudes north -> south: flipped like functions.py:822-829 (the pole
+        src_lat = src_lat[::-1].copy()             # rows then depend on the sign of dlat_gcm, taken BEFORE the flip, :779)
+        f = np.ascontiguousarray(f[..., ::-1, :])
     f32 = rng.random() < 0.3
     if f32:
         f = f.astype(np.float32)
