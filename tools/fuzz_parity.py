@@ -53,10 +53,24 @@ def one(rng, i, run=True, debug=False):
     if rng.random() < 0.3:                              # ps_hist above every delta level somewhere
         d['ps_hist'] = d['ps_hist'].copy()
         d['ps_hist'][:, rng.integers(0, nlat), rng.integers(0, nlon)] = 104000.0
-    args = (c['era'], d, c['delta_times'], c['plev'], c['target_dt'], True)
+    ignore_top = True
+    inject = None
+    if rng.random() < 0.12 and mode == 'file':          # data errors: both sides must raise the reference's exception
+        inject = str(rng.choice(['ps_hist_low', 'ps_nan', 'ps_below_p_ref', 'top_check']))
+        jj, ii = int(rng.integers(0, nlat)), int(rng.integers(0, nlon))
+        if inject == 'ps_hist_low':                     # ValueError() of replace_delta_sfc, functions.py:360-361
+            d['ps_hist'] = d['ps_hist'].copy(); d['ps_hist'][:, jj, ii] = 50.0
+        elif inject == 'ps_nan':                        # all-NaN p_diff column, functions.py:162-165
+            c['era']['PS'] = c['era']['PS'].copy(); c['era']['PS'][0, jj, ii] = np.nan
+        elif inject == 'ps_below_p_ref':                # surface above the reference level
+            c['era']['PS'] = c['era']['PS'].copy(); c['era']['PS'][0, jj, ii] = 25000.0
+        else:
+            ignore_top = False                          # the model top of the synthetic levels lies above the delta top
+    args = (c['era'], d, c['delta_times'], c['plev'], c['target_dt'], ignore_top)
     if not run:
         return None, 'skip'
-    desc = dict(i=i, shape=[nlat, nlon, nlev], dtype=np.dtype(dtype).name, mode=str(mode), S=int(len(plev)), target=str(c['target_dt']))
+    desc = dict(i=i, shape=[nlat, nlon, nlev], dtype=np.dtype(dtype).name, mode=str(mode), S=int(len(plev)), target=str(c['target_dt']),
+                inject=inject)
     try:
         if mode == 'reinterp':
             got = s3.pgw_for_era5_arrays(*args, i_reinterp=True)
@@ -93,7 +107,9 @@ def one(rng, i, run=True, debug=False):
         try:
             (O.pgw_for_era5_arrays_reinterp if mode == 'reinterp' else (R if dtype == np.float32 else O).pgw_for_era5_arrays)(*args)
         except Exception as e2:                         # noqa: BLE001
-            return desc, 'both raise: %s / %s' % (type(e).__name__, type(e2).__name__)
+            same = type(e) is type(e2) and (str(e) == str(e2) or not str(e2) or str(e).startswith(str(e2).rstrip('.!')[:40]))
+            return desc, ('both raise: %s' % type(e).__name__) if same else \
+                'different errors: %s: %s / %s: %s' % (type(e).__name__, str(e)[:120], type(e2).__name__, str(e2)[:120])
         return desc, 'HIP raises alone: %s: %s' % (type(e).__name__, e)
     bad = []
     if got['n_iter'] != want['n_iter']:
