@@ -401,6 +401,14 @@ int pgw_gauss_interp(pgw_ctx *ctx, long long ntarg, const double *tx, const doub
                      double x0, double y0, double cell, const int *cell_start, long long nsrc, const double *sx,
                      const double *sy, const double *sval, int nfield, double radius, double sharpness, double *out);
 
+/* The planar "metre" coordinates of that interpolation (functions.py:958-975, 1010-1023: per point three
+ * pyproj.Geod(ellps="WGS84").inv lengths - the meridian arc from the equator, the geodesic between (0, lat) and
+ * (lon, lat), and the one between (0, lat) and (180, lat)) for n points: lat, lon [deg], lon in (-180, 180]; outputs
+ * lat_m = sign(lat) * arc, lon_m = sign(lon) * geodesic, lon_off = over-the-pole length [m].  Device pointers.  Vincenty's
+ * series arranged as in pgw4era5_amd/geodesy.py (bisection on the departure azimuth; no iteration that can fail). */
+int pgw_planar_metres(pgw_ctx *ctx, long long n, const double *lat, const double *lon, double *lat_m, double *lon_m,
+                      double *lon_off);
+
 /* Byte-order conversion on the device: dst[i] = byte-reversed src[i] for n elements of 4 or 8 bytes (in place
  * allowed).  NetCDF classic files are big-endian (the reference reads / writes them through xarray,
  * step_03_apply_to_era.py:60, 378, which converts on the host); with this entry the raw file bytes are uploaded

@@ -129,6 +129,7 @@ SIGNATURES['pgw_byteswap'] = (_i, [_vp, _i, _ll, _vp, _vp])
 SIGNATURES['pgw_narrow_f64_f32'] = (_i, [_vp, _ll, _vp, _vp, _i])
 SIGNATURES['pgw_harmonic_smooth'] = (_i, [_vp, _i, _i, _ll, _dp, _dp, _vp, _vp])
 SIGNATURES['pgw_gauss_interp'] = (_i, [_vp, _ll, _vp, _vp, _i, _i, _d, _d, _d, _vp, _ll, _vp, _vp, _vp, _i, _d, _d, _vp])
+SIGNATURES['pgw_planar_metres'] = (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp])
 
 _lib = None
 

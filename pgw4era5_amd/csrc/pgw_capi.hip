@@ -1516,6 +1516,16 @@ extern "C" int pgw_gauss_interp(pgw_ctx *ctx, long long ntarg, const double *tx,
     return PGW_OK;
 }
 
+extern "C" int pgw_planar_metres(pgw_ctx *ctx, long long n, const double *lat, const double *lon, double *lat_m, double *lon_m,
+                                 double *lon_off) {
+    NEED(ctx, n >= 0 && (n == 0 || (lat && lon && lat_m && lon_m && lon_off)), "bad argument");
+    if (n == 0) return PGW_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_planar_metres, dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, n, lat, lon, lat_m, lon_m, lon_off);
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
 extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst) {
     NEED(ctx, elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 or 8");
     NEED(ctx, n >= 0 && (n == 0 || (src && dst)), "bad argument");

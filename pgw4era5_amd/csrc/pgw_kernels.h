@@ -2414,6 +2414,85 @@ __global__ __launch_bounds__(BLOCK) void k_gauss_interp(long long ntarg, const d
 }
 
 // float64 -> float32 (round to nearest even, the conversion numpy's astype does), two elements per lane, optionally byte-reversed
+// -------------------------------------------------------------------------------------
+// Planar "metre" coordinates of the ocean-grid interpolation (functions.py:958-975, 1010-1023: three pyproj Geod.inv
+// calls per point) on the GPU: the arithmetic of pgw4era5_amd/geodesy.py (Vincenty's series arranged so that nothing
+// iterates to failure - meridian arc and over-the-pole length from the direct series with azimuth 0, the geodesic between
+// two points of one parallel by bisection on the departure azimuth), one point per thread.  Same formulas and iteration
+// count as the host form; sin / cos / atan2 are the device library's, so results agree to the last bits (~1e-9 m), not
+// bit for bit.
+// -------------------------------------------------------------------------------------
+namespace geo {
+constexpr double A = 6378137.0, F = 1.0 / 298.257223563, B = A * (1.0 - F), PI = 3.14159265358979323846;
+struct Series { double a, b, c; };
+__device__ __forceinline__ Series series(double cos2_alpha) {
+    const double u2 = cos2_alpha * (A * A - B * B) / (B * B);
+    Series s;
+    s.a = 1 + u2 / 16384 * (4096 + u2 * (-768 + u2 * (320 - 175 * u2)));
+    s.b = u2 / 1024 * (256 + u2 * (-128 + u2 * (74 - 47 * u2)));
+    s.c = F / 16 * cos2_alpha * (4 + F * (4 - 3 * cos2_alpha));
+    return s;
+}
+__device__ __forceinline__ double arc(double sigma, double cos_2sm, double a, double b) {
+    const double sin_s = sin(sigma), cos_s = cos(sigma);
+    const double dsig = b * sin_s * (cos_2sm + b / 4 * (cos_s * (-1 + 2 * cos_2sm * cos_2sm) -
+                                                        b / 6 * cos_2sm * (-3 + 4 * sin_s * sin_s) * (-3 + 4 * cos_2sm * cos_2sm)));
+    return B * a * (sigma - dsig);
+}
+__device__ __forceinline__ double reduced_latitude(double lat_deg) { return atan((1.0 - F) * tan(lat_deg * (PI / 180.0))); }
+__device__ __forceinline__ double meridian_arc(double lat_deg) {
+    double U = fabs(reduced_latitude(lat_deg));
+    if (fabs(lat_deg) >= 90.0) U = 0.5 * PI;
+    const Series s = series(1.0);
+    return arc(U, cos(U), s.a, s.b);
+}
+// leave reduced latitude U (>= 0) with azimuth a1 in [0, pi/2], travel until latitude U is reached again
+__device__ __forceinline__ void symmetric(double U, double a1, double &L, double &len) {
+    const double sinU = sin(U), cosU = cos(U), sin_a1 = sin(a1), cos_a1 = cos(a1);
+    const double s1 = atan2(sinU, cosU * cos_a1);
+    const double sigma = PI - 2.0 * s1;
+    const double sin_alpha = cosU * sin_a1;
+    const double cos2_alpha = 1.0 - sin_alpha * sin_alpha;
+    const Series s = series(cos2_alpha);
+    const double sin_s = sin(sigma), cos_s = cos(sigma);
+    double omega = atan2(sin_s * sin_a1, cosU * cos_s - sinU * sin_s * cos_a1);
+    if (omega < 0) omega += 2 * PI;
+    const double cos_2sm = -1.0;
+    L = omega - (1 - s.c) * F * sin_alpha * (sigma + s.c * sin_s * (cos_2sm + s.c * cos_s * (-1 + 2 * cos_2sm * cos_2sm)));
+    len = arc(sigma, cos_2sm, s.a, s.b);
+}
+}  // namespace geo
+
+// lat, lon [deg] (lon folded to (-180, 180] by the caller) -> lat_m, lon_m, lon_off; quarter = meridian_arc(90)
+__global__ __launch_bounds__(BLOCK) void k_planar_metres(long long n, const double *__restrict__ lat, const double *__restrict__ lon,
+                                                        double *__restrict__ lat_m, double *__restrict__ lon_m,
+                                                        double *__restrict__ lon_off) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double la = lat[i], lo = lon[i];
+    const double quarter = geo::meridian_arc(90.0);
+    const double arc_m = geo::meridian_arc(la);
+    const double over_pole = 2.0 * (quarter - arc_m);
+    const double sgn_la = (la > 0) - (la < 0), sgn_lo = (lo > 0) - (lo < 0);
+    const double dl = fabs(lo), U = fabs(geo::reduced_latitude(la)), Ls = dl * (geo::PI / 180.0);
+    double a_lo = 0.0, a_hi = 0.5 * geo::PI, L, len;
+    for (int it = 0; it < 70; ++it) {
+        const double mid = 0.5 * (a_lo + a_hi);
+        geo::symmetric(U, mid, L, len);
+        if (L > Ls) a_lo = mid; else a_hi = mid;
+    }
+    geo::symmetric(U, 0.5 * (a_lo + a_hi), L, len);
+    double s = len;
+    if (U < 1e-15 && Ls <= (1.0 - geo::F) * geo::PI) s = geo::A * Ls;      // the equator itself
+    if (dl >= 180.0) s = over_pole;
+    if (fabs(la) >= 90.0) s = 0.0;
+    if (dl == 0.0) s = 0.0;
+    if (la != la || lo != lo) s = __builtin_nan("");
+    lat_m[i] = arc_m * sgn_la;
+    lon_m[i] = s * sgn_lo;
+    lon_off[i] = over_pole;
+}
+
 template <bool SWAP>
 __global__ __launch_bounds__(BLOCK) void k_narrow_f64_f32(long long n2, long long n, const double *__restrict__ src, unsigned int *__restrict__ dst) {
     typedef double d2 __attribute__((ext_vector_type(2)));

@@ -654,6 +654,25 @@ def _fold_lon(lon):
     return lon
 
 
+def planar_metres(lat_deg, lon_deg):
+    """The reference's point-cloud coordinates (functions.py:958-975, 1010-1023: three pyproj Geod.inv lengths per point) on
+    the GPU (`pgw_planar_metres`): (lat_m, lon_m, lon_offset) in metres for latitudes / longitudes in degrees, longitudes
+    already folded to (-180, 180].  The arithmetic is pgw4era5_amd/geodesy.py's (the host form, kept as the check)."""
+    ctx = default_context()
+    lat = np.ascontiguousarray(lat_deg, dtype=np.float64).reshape(-1)
+    lon = np.ascontiguousarray(lon_deg, dtype=np.float64).reshape(-1)
+    if lat.shape != lon.shape:
+        raise ValueError('latitudes and longitudes must have the same number of points')
+    n = len(lat)
+    if n == 0:
+        return np.zeros(0), np.zeros(0), np.zeros(0)
+    f64 = np.dtype('float64')
+    d_lat, d_lon = ctx.to_device(lat, f64), ctx.to_device(lon, f64)
+    outs = [ctx.empty((n,), f64) for _ in range(3)]
+    ctx._check(ctx.lib.pgw_planar_metres(ctx.handle, n, d_lat.ptr, d_lon.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr))
+    return tuple(o.numpy() for o in outs)
+
+
 def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, kernel_radius, sharpness):
     """The geometry and the GPU pass of nan_ignoring_interp for SEVERAL fields on the same source points (the twelve
     months of a variable: interp_wrapper calls nan_ignoring_interp once per month, functions.py:1102-1109, rebuilding
@@ -670,7 +689,7 @@ def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, k
     nf = vals.shape[1]
     keep = ~np.isnan(vals).all(axis=1)                         # :944-948 (a point that is NaN in every field is in no cloud)
     glat, glon, vals = glat[keep], glon[keep], vals[keep]
-    lat_m, lon_m, lon_off = geodesy.planar_metres(glat, glon)                                   # :958-975
+    lat_m, lon_m, lon_off = planar_metres(glat, glon)                                           # :958-975
     # :977-991 the whole field once more to the left and to the right, shifted by twice the half-way-round length
     sx = np.tile(lat_m, 3)
     sy = np.concatenate([lon_m - 2 * lon_off, lon_m, lon_m + 2 * lon_off])
@@ -681,8 +700,10 @@ def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, k
     # lat_m depends on the latitude only, lon_m on (|lat|, |lon|): evaluate the distinct values of the regular grid once
     la_u, la_i = np.unique(np.abs(elat), return_inverse=True)
     lo_u, lo_i = np.unique(np.abs(elon), return_inverse=True)
-    lat_arc = geodesy.meridian_arc(la_u)
-    lon_arc = geodesy.same_latitude_geodesic(la_u[:, None], lo_u[None, :])
+    uu_lat, uu_lon = np.repeat(la_u, len(lo_u)), np.tile(lo_u, len(la_u))
+    u_arc, u_lon, _ = planar_metres(uu_lat, uu_lon)
+    lat_arc = u_arc.reshape(len(la_u), len(lo_u))[:, 0]
+    lon_arc = u_lon.reshape(len(la_u), len(lo_u))
     tx = (lat_arc[la_i] * np.sign(elat))[:, None] * np.ones(len(elon))[None, :]
     ty = lon_arc[np.ix_(la_i, lo_i)] * np.sign(elon)[None, :]
     tx, ty = np.ascontiguousarray(tx.reshape(-1)), np.ascontiguousarray(ty.reshape(-1))

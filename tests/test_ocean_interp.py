@@ -41,6 +41,25 @@ def _era_grid(nlat, nlon):
 
 
 @pytest.mark.gpu
+def test_planar_metres_on_the_gpu_equals_the_host_geodesy():
+    """pgw_planar_metres (one thread per point: meridian arc, same-parallel geodesic by bisection, over-the-pole length)
+    against pgw4era5_amd/geodesy.py - the same formulas in numpy - incl. the poles, the equator up to and beyond
+    (1 - f) 180 deg, lon = 0 and +-180, and against the oracle's Vincenty inverse where that converges."""
+    from pgw4era5_amd import functions as F, geodesy as G
+    rng = np.random.default_rng(4)
+    lat = np.concatenate([rng.uniform(-90, 90, 4000), [0.0, 0.0, 0.0, 0.0, 90.0, -90.0, 45.0, 45.0, 1e-9, -37.0, 0.0]])
+    lon = np.concatenate([rng.uniform(-180, 180, 4000), [179.0, 179.7, -179.9, 180.0, 33.0, -120.0, 0.0, 180.0, 170.0, -180.0, 0.0]])
+    got = F.planar_metres(lat, lon)
+    want = G.planar_metres(lat, lon)
+    for g, w, name in zip(got, want, ('lat_m', 'lon_m', 'lon_off')):
+        np.testing.assert_allclose(g, w, rtol=0, atol=2e-6, err_msg=name)           # metres
+    la, lo = rng.uniform(-89, 89, 300), rng.uniform(-179, 179, 300)
+    for g, w in zip(F.planar_metres(la, lo), O.planar_metres(la, lo)):
+        np.testing.assert_allclose(g, w, rtol=0, atol=1e-4)
+    assert all(len(x) == 0 for x in F.planar_metres(np.zeros(0), np.zeros(0)))
+
+
+@pytest.mark.gpu
 def test_gauss_interp_vs_oracle_small():
     from pgw4era5_amd import functions as F, synthetic
     oc = synthetic.make_ocean_grid_case(nj=18, ni=26, ntime=3, seed=2)
