@@ -706,6 +706,19 @@ def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, k
     lon_arc = u_lon.reshape(len(la_u), len(lo_u))
     tx = (lat_arc[la_i] * np.sign(elat))[:, None] * np.ones(len(elon))[None, :]
     ty = lon_arc[np.ix_(la_i, lo_i)] * np.sign(elon)[None, :]
+    # the kernel stages the source cells a BLOCK of 256 consecutive targets needs, and a wave runs the weight arithmetic of a
+    # source point when ANY of its 64 lanes has the point within the radius: hand the targets over in tiles of 16 x 16 grid
+    # points (one block; a wave = 4 x 16 of them) instead of row by row - a compact footprint, so few cells per block and
+    # few accepted points per wave that most of its lanes reject.  Edge tiles are filled with NaN (inactive) targets.
+    nlat_t, nlon_t = tx.shape
+    TILE = 16
+    nlat_p, nlon_p = -(-nlat_t // TILE) * TILE, -(-nlon_t // TILE) * TILE
+
+    def tiles(a):
+        full = np.full((nlat_p, nlon_p), np.nan)
+        full[:nlat_t, :nlon_t] = a
+        return full.reshape(nlat_p // TILE, TILE, nlon_p // TILE, TILE).transpose(0, 2, 1, 3)
+    tx, ty = tiles(tx), tiles(ty)
     tx, ty = np.ascontiguousarray(tx.reshape(-1)), np.ascontiguousarray(ty.reshape(-1))
     # uniform cells of one kernel radius over the source cloud
     h = float(kernel_radius)
@@ -736,6 +749,8 @@ def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, k
         ctx._check(ctx.lib.pgw_gauss_interp(ctx.handle, ntarg, d_tx.ptr, d_ty.ptr, ncx, ncy, x0, y0, h, d_cs.ptr, len(sx),
                                             d_sx.ptr, d_sy.ptr, d_sub.ptr, k1 - k0, float(kernel_radius), float(sharpness), d_out.ptr))
         out[k0:k1] = d_out.numpy()
+    out = out.reshape(nf, nlat_p // TILE, nlon_p // TILE, TILE, TILE).transpose(0, 1, 3, 2, 4).reshape(nf, nlat_p, nlon_p)
+    out = np.ascontiguousarray(out[:, :nlat_t, :nlon_t]).reshape(nf, -1)
     land = np.asarray(land_fr, dtype=np.float64).reshape(-1)
     out[:, land > 0.7] = np.nan                               # :1032, 1055: no SST on land points
     return out.reshape(nf, len(elat), len(elon))
