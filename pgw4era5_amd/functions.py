@@ -714,10 +714,16 @@ def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, k
     TILE = 16
     nlat_p, nlon_p = -(-nlat_t // TILE) * TILE, -(-nlon_t // TILE) * TILE
 
+    # tiles of the high latitudes first: the planar cloud is densest there (a parallel shrinks, the points on it do not get
+    # fewer), so those blocks run longest; started first they do not form the tail of the launch
+    nty, ntx = nlat_p // TILE, nlon_p // TILE
+    row_lat = np.abs(np.pad(elat, (0, nlat_p - nlat_t), mode='edge').reshape(nty, TILE)).mean(axis=1)
+    tile_order = np.argsort(-np.repeat(row_lat, ntx), kind='stable')
+
     def tiles(a):
         full = np.full((nlat_p, nlon_p), np.nan)
         full[:nlat_t, :nlon_t] = a
-        return full.reshape(nlat_p // TILE, TILE, nlon_p // TILE, TILE).transpose(0, 2, 1, 3)
+        return full.reshape(nty, TILE, ntx, TILE).transpose(0, 2, 1, 3).reshape(nty * ntx, TILE * TILE)[tile_order]
     tx, ty = tiles(tx), tiles(ty)
     tx, ty = np.ascontiguousarray(tx.reshape(-1)), np.ascontiguousarray(ty.reshape(-1))
     # uniform cells of one kernel radius over the source cloud
@@ -749,7 +755,10 @@ def gauss_interp_fields(land_fr, era5_lat, era5_lon, gcm_lat, gcm_lon, fields, k
         ctx._check(ctx.lib.pgw_gauss_interp(ctx.handle, ntarg, d_tx.ptr, d_ty.ptr, ncx, ncy, x0, y0, h, d_cs.ptr, len(sx),
                                             d_sx.ptr, d_sy.ptr, d_sub.ptr, k1 - k0, float(kernel_radius), float(sharpness), d_out.ptr))
         out[k0:k1] = d_out.numpy()
-    out = out.reshape(nf, nlat_p // TILE, nlon_p // TILE, TILE, TILE).transpose(0, 1, 3, 2, 4).reshape(nf, nlat_p, nlon_p)
+    back = np.empty_like(tile_order)
+    back[tile_order] = np.arange(len(tile_order))
+    out = out.reshape(nf, nty * ntx, TILE * TILE)[:, back]
+    out = out.reshape(nf, nty, ntx, TILE, TILE).transpose(0, 1, 3, 2, 4).reshape(nf, nlat_p, nlon_p)
     out = np.ascontiguousarray(out[:, :nlat_t, :nlon_t]).reshape(nf, -1)
     land = np.asarray(land_fr, dtype=np.float64).reshape(-1)
     out[:, land > 0.7] = np.nan                               # :1032, 1055: no SST on land points
