@@ -795,12 +795,28 @@ def rocprof_frac(kernel, a, algo_GB):
     if not files:
         return {}
     pat = PMC_KERNEL.get(kernel, '?')
-    for r in csv.DictReader(open(files[-1])):
-        if r['kernel'].startswith(pat) and _instantiation_ok(r['kernel'], a) and 'timed_avg_us' in r and r['timed_avg_us']:
-            avg = float(r['timed_avg_us'])
-            return {'frac_rocprof': round(algo_GB / (avg / 1e6) / HBM_PEAK_GBS, 4), 'rocprof_timed_avg_launch_ms': round(avg / 1e3, 4),
-                    'rocprof_timed_launches': int(r['timed_calls']), 'rocprof_source': os.path.relpath(files[-1], ROOT)}
-    return {}
+
+    def row_of(path):
+        for r in csv.DictReader(open(path)):
+            if r['kernel'].startswith(pat) and _instantiation_ok(r['kernel'], a) and r.get('timed_avg_us'):
+                return r
+        return None
+    # the latest committed summary is THE figure; the round's other summaries are listed beside it (tag -> fraction): r02k, r02m
+    # and r02n are the same float64 quad kernel on three boxes of the pool (it differs by 10 % between boxes), earlier tags are
+    # earlier builds of the round
+    every = {}
+    for f in files:
+        r = row_of(f)
+        tag = os.path.basename(f)[len('kernel_stats_'):].split('_')[0]
+        if r is not None and tag.startswith('r02'):
+            every[tag] = round(algo_GB / (float(r['timed_avg_us']) / 1e6) / HBM_PEAK_GBS, 4)
+    r = row_of(files[-1])
+    if r is None:
+        return {}
+    avg = float(r['timed_avg_us'])
+    return {'frac_rocprof': round(algo_GB / (avg / 1e6) / HBM_PEAK_GBS, 4), 'rocprof_timed_avg_launch_ms': round(avg / 1e3, 4),
+            'rocprof_timed_launches': int(r['timed_calls']), 'rocprof_source': os.path.relpath(files[-1], ROOT),
+            'frac_rocprof_by_committed_profile': every}
 
 
 def pmc_traffic(kernel, a):
