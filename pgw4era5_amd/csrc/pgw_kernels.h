@@ -1129,8 +1129,9 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
         };
         int j = 0;
         double xprev = -__builtin_inf();
-        int wdiv = -1;                                  // window position by_W belongs to
-        SharedDivisor by_W(1.0, 1.0);
+        int wdiv = -1, ddiv = -2;                       // window position by_W / delta bracket by_D belong to
+        SharedDivisor by_W(1.0, 1.0), by_D(1.0, 1.0);
+        double dx1 = 0.0;
         for (int l0 = 0; l0 < N; l0 += RING_LEAD) {
 #pragma unroll
             for (int u = 0; u < RING_LEAD; ++u) {
@@ -1181,8 +1182,8 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
                     fetch(i1);
                     double y0 = a_lo, y1 = b_lo;
                     if (i1 != i2) {
-                        const double x1 = srcx(i1);
-                        const SharedDivisor by_D(srcx(i2) - x1);
+                        if (ddiv != i1) { dx1 = srcx(i1); by_D = SharedDivisor(srcx(i2) - dx1); ddiv = i1; }   // once per delta bracket
+                        const double x1 = dx1;
                         const double dx = x - x1;
                         y0 = a_lo + by_D.divide(dx * (a_hi - a_lo));
                         y1 = b_lo + by_D.divide(dx * (b_hi - b_lo));
