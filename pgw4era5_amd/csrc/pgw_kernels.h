@@ -1083,6 +1083,13 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
         // delta records of the bracket (ci, ci + 1) of both variables; all loads of a change before the first use
         int ci = -2;
         double a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;
+        const bool lerp = rv.d[0].a != nullptr;          // one instant for every record of the launch
+        const double x_new = rv.d[0].x_new;
+        const SharedDivisor by_x_hi(lerp ? rv.d[0].x_hi : 1.0);
+        auto tl = [&](T rb, T ra) -> double {             // DeltaSrc::get (functions.py:282-292)
+            if (!lerp) return (double)rb;
+            return by_x_hi.divide((double)ra - (double)rb) * x_new + (double)rb;
+        };
         auto fetch = [&](int i1) {
             if (ci == i1) return;
             const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
@@ -1090,8 +1097,12 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
             const bool seq = (ci + 1 == i1);
             const bool need_h = !is_sfc(ih), need_l = !seq && !is_sfc(i1);
             double h0 = 0, h1 = 0, l0 = 0, l1 = 0;
-            if (need_h) { h0 = rv.d[0].get_off(oh); h1 = rv.d[1].get_off(oh); }
-            if (need_l) { l0 = rv.d[0].get_off(ol); l1 = rv.d[1].get_off(ol); }
+            // raw records first, then the time interpolation (the quotient by the launch-wide x_hi through one reciprocal)
+            T hb0 = 0, hb1 = 0, ha0 = 0, ha1 = 0, lb0 = 0, lb1 = 0, la0 = 0, la1 = 0;
+            if (need_h) { hb0 = ld_off(rv.d[0].b, oh); hb1 = ld_off(rv.d[1].b, oh); if (lerp) { ha0 = ld_off(rv.d[0].a, oh); ha1 = ld_off(rv.d[1].a, oh); } }
+            if (need_l) { lb0 = ld_off(rv.d[0].b, ol); lb1 = ld_off(rv.d[1].b, ol); if (lerp) { la0 = ld_off(rv.d[0].a, ol); la1 = ld_off(rv.d[1].a, ol); } }
+            if (need_h) { h0 = tl(hb0, ha0); h1 = tl(hb1, ha1); }
+            if (need_l) { l0 = tl(lb0, la0); l1 = tl(lb1, la1); }
             if (seq) { a_lo = a_hi; b_lo = b_hi; }
             else { a_lo = need_l ? l0 : d_sfc0; b_lo = need_l ? l1 : d_sfc1; }
             a_hi = need_h ? h0 : d_sfc0;
