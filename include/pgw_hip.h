@@ -434,6 +434,14 @@ int pgw_test_log_table(pgw_ctx *ctx, long long n, const double *in, double *out)
  * out == ref bit for bit and <= 1 ulp from numpy. */
 int pgw_test_exp(pgw_ctx *ctx, long long n, const double *in, double *out, double *ref);
 
+/* diagnostic: RELHUM of a float32 ERA state as numpy's promotion evaluates functions.py:58-116 on float32 files
+ * (reference-dtype mode, step_03_apply_to_era.py:91-94): out = the form the quad kernel uses (the one phase a temperature
+ * needs, scale-free divisions, expf without range selects), lit = the expression as written (both phases, IEEE divisions,
+ * library expf); es / es_lit = the float32 e_sat alone.  hus, ta float32, pa float64; device arrays.  Tests require
+ * out == lit and es == es_lit bit for bit over the physical range and the same special values outside it. */
+int pgw_test_rh_f32(pgw_ctx *ctx, long long n, const float *hus, const double *pa, const float *ta,
+                    double *out, double *lit, float *es, float *es_lit);
+
 /* diagnostic: out[i] = num[i] / den[i] through the shared-divisor path (pgw_device.h SharedDivisor: reciprocal once,
  * three instructions per quotient) that the regridding and delta kernels use where many numerators share a divisor;
  * device fp64 arrays.  Tests require the IEEE quotient bit for bit. */

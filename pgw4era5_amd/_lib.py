@@ -125,6 +125,7 @@ SIGNATURES['pgw_test_log'] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES['pgw_test_log_table'] = (_i, [_vp, _ll, _vp, _vp])
 SIGNATURES['pgw_test_exp'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_test_shared_div'] = (_i, [_vp, _ll, _vp, _vp, _vp])
+SIGNATURES['pgw_test_rh_f32'] = (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES['pgw_byteswap'] = (_i, [_vp, _i, _ll, _vp, _vp])
 SIGNATURES['pgw_narrow_f64_f32'] = (_i, [_vp, _ll, _vp, _vp, _i])
 SIGNATURES['pgw_harmonic_smooth'] = (_i, [_vp, _i, _i, _ll, _dp, _dp, _vp, _vp])

@@ -808,7 +808,6 @@ extern "C" int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, 
     if (rc) return rc;
     if ((rc = status_reset(ctx))) return rc;
     Levels lv = levels_of(ctx);
-    const long long total = (long long)ntime * ncol;
     {
         Prof pr(ctx, PGW_K_VERT_INTERP_DELTA);
         DISPATCH_T(dtype, {
@@ -1461,6 +1460,14 @@ extern "C" unsigned long long pgw_last_levels_touched(pgw_ctx *ctx) { return ctx
 extern "C" int pgw_test_exp(pgw_ctx *ctx, long long n, const double *in, double *out, double *ref) {
     NEED(ctx, n >= 1 && in && out && ref, "bad argument");
     hipLaunchKernelGGL(k_test_exp, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, in, out, ref);
+    HIPCHK(ctx, hipGetLastError());
+    return PGW_OK;
+}
+
+extern "C" int pgw_test_rh_f32(pgw_ctx *ctx, long long n, const float *hus, const double *pa, const float *ta,
+                               double *out, double *lit, float *es, float *es_lit) {
+    NEED(ctx, n >= 1 && hus && pa && ta && out && lit && es && es_lit, "bad argument");
+    hipLaunchKernelGGL(k_test_rh_f32, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, n, hus, pa, ta, out, lit, es, es_lit);
     HIPCHK(ctx, hipGetLastError());
     return PGW_OK;
 }

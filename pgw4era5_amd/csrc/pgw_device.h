@@ -251,7 +251,8 @@ __device__ __forceinline__ double pgw_log_tab(double x, const double *tab) {
 // Same operations and constants, hence the same bits as exp() (tests/...::test_device_exp_is_library_exp); the point
 // is code generation: for most of the inlined library instances in the delta kernels the compiler forms each Horner
 // step as v_mov_b64 (copy of the coefficient) + v_fmac, two instructions, where one three-address v_fma_f64 does.
-__device__ __forceinline__ double pgw_exp(double x) {
+template <bool RANGE>
+__device__ __forceinline__ double pgw_exp_impl(double x) {
     const double n = __builtin_rint(x * 0x1.71547652b82fep+0);
     double r = __builtin_fma(-0x1.62e42fefa39efp-1, n, x);
     r = __builtin_fma(-0x1.abc9e3b39803fp-56, n, r);
@@ -267,10 +268,16 @@ __device__ __forceinline__ double pgw_exp(double x) {
     p = __builtin_fma(r, p, 1.0);
     p = __builtin_fma(r, p, 1.0);
     double v = __builtin_ldexp(p, (int)n);
-    v = (1024.0 < x) ? __builtin_inf() : v;          // NaN compares false: the NaN from the arithmetic is kept
-    v = (x < -1075.0) ? 0.0 : v;
+    if (RANGE) {
+        v = (1024.0 < x) ? __builtin_inf() : v;      // NaN compares false: the NaN from the arithmetic is kept
+        v = (x < -1075.0) ? 0.0 : v;
+    }
     return v;
 }
+__device__ __forceinline__ double pgw_exp(double x) { return pgw_exp_impl<true>(x); }
+// without the library's two range selects: the same bits for every finite x (v_ldexp_f64 saturates to 0 / inf by itself,
+// the conversion of n saturates too) and for NaN; only x = +-inf gives NaN instead of inf / 0.  For arguments of known range.
+__device__ __forceinline__ double pgw_exp_finite(double x) { return pgw_exp_impl<false>(x); }
 
 // ---- humidity thermodynamics (functions.py:58-125), operation order as written there ----
 __device__ __forceinline__ double esat_water(double ta) {   // :74-89 water
@@ -300,8 +307,7 @@ __device__ __forceinline__ double esat_special(double ta, double e1) {
     }
     if (ta <= 40.0) {                                            // unphysical cold: the literal expression, 0 * e_w may be NaN / inf
         const double ew = 611.21 * pgw_exp(17.502 * (ta - 273.16) / (ta - 32.19));     // IEEE division: the divisor is 0 at 32.19 K
-        // e1 is e_i here; its scale-free division differs from the IEEE one only where ta + 0.7 == 0: exp(-inf) = 0
-        const double ei = (ta == -0.7) ? 0.0 : e1;
+        const double ei = 611.21 * pgw_exp(22.587 * (ta - 273.16) / (ta - (-0.7)));    // and at -0.7 K: exp(-inf) = 0
         return 0.0 * ew + 1.0 * ei;
     }
     return __builtin_nan("");                                    // NaN temperature
@@ -311,7 +317,8 @@ __device__ __forceinline__ double esat_mixed(double ta) {
     const bool warm = (ta >= T0);
     const double a3 = warm ? 17.502 : 22.587;
     const double a4 = warm ? 32.19 : -0.7;
-    double e1 = 611.21 * pgw_exp(div_ns(a3 * (ta - T0), ta - a4));   // e_w if warm else e_i (NaN for NaN ta)
+    // e_w if warm else e_i (NaN for NaN ta); |argument| < 130 for every T the value is used for: no range selects
+    double e1 = 611.21 * pgw_exp_finite(div_ns(a3 * (ta - T0), ta - a4));
     // ONE divergent region per call (every branch costs scalar instructions and issue slots the few resident waves of the
     // delta kernels cannot hide): e1 is the answer for T >= T0 and for 40 K < T <= Ti
     if (__builtin_expect(!(warm || (ta <= Ti && ta > 40.0)), 0)) e1 = esat_special(no_speculate(ta), e1);
@@ -323,6 +330,10 @@ __device__ __forceinline__ double q_to_e(double hus, double pa) {          // :5
 __device__ __forceinline__ double e_to_q(double vapp, double pa) {         // :66-72
     return CON_MW_MD * vapp / (pa - (1 - CON_MW_MD) * vapp);
 }
+// the same with the scale-free quotient, for pressures of the model's levels (pa - 0.378 e is a pressure of known range)
+__device__ __forceinline__ double e_to_q_ns(double vapp, double pa) {
+    return div_ns(CON_MW_MD * vapp, pa - (1 - CON_MW_MD) * vapp);
+}
 __device__ __forceinline__ double q_to_rh(double hus, double pa, double ta) {   // :107-116
     return div_ns(q_to_e(hus, pa), esat_mixed(ta)) * 100;
 }
@@ -333,7 +344,8 @@ __device__ __forceinline__ double q_to_rh(double hus, double pa, double ta) {   
 __device__ __forceinline__ float esat_x_f32(float ta, float a3, float a4) {
     return 611.21f * expf(a3 * (ta - 273.16f) / (ta - a4));
 }
-__device__ __forceinline__ float esat_mixed_f32(float ta) {
+// the expression as written (:91-105): both phases, IEEE divisions, the library's expf
+__device__ __forceinline__ float esat_mixed_f32_literal(float ta) {
     const float T0 = 273.16f, Ti = 250.16f;
     float alpha = __builtin_nanf("");
     if (ta >= T0) alpha = 1.0f;
@@ -341,10 +353,61 @@ __device__ __forceinline__ float esat_mixed_f32(float ta) {
     if (ta < T0 && ta > Ti) { const float r = (ta - Ti) / 23.0f; alpha = r * r; }   // (T0 - Ti) = 23.000000000000028 -> 23.0f
     return alpha * esat_x_f32(ta, 17.502f, 32.19f) + (1.0f - alpha) * esat_x_f32(ta, 22.587f, -0.7f);
 }
-// hus float32, pa float64 (ak/bk are float64): hus*pa is float64, the denominator CON_MW_MD + 0.378*hus float32 (:63)
+// n / d in float32 by the compiler's own IEEE sequence without v_div_scale (x2) and v_div_fixup: v_rcp_f32, one Newton
+// step, q = n r, two residual corrections - 8 instead of 11 instructions and the same bits whenever neither operand
+// needs scaling (div_ns above is the float64 form).  Used for a3 (T - T0) / (T - a4) with 60 K < T < 10^4 K.
+__device__ __forceinline__ float div_ns_f32(float n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+// the device library's expf arithmetic - x log2(e) as a float32 pair, n = rint, v_exp_f32 of the remainder, ldexp -
+// without its two range selects (callers keep |x| < 87): the same bits as expf() there
+// (tests/...::test_reference_mode_esat_f32_fast_path_is_the_literal_expression)
+__device__ __forceinline__ float pgw_expf_core(float x) {
+    const float log2e = 0x1.715476p+0f;                        // 0x3fb8aa3b
+    const float ph = x * log2e;
+    float pl = __builtin_fmaf(x, log2e, -ph);
+    pl = __builtin_fmaf(x, __uint_as_float(0x32a5705fu), pl);   // + x * (log2(e) - float(log2(e)))
+    const float n = __builtin_rintf(ph);
+    const float a = (ph - n) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)n);
+}
+__device__ __forceinline__ float no_speculate_f(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// alpha e_w + (1 - alpha) e_i for alpha in {0, 1} is exactly the phase the temperature needs: the dropped term is
+// 0 * finite = +0 and x + 0 = x in float32 as in float64 (esat_mixed above).  One division and one exponential for
+// T >= T0 (water) and for 60 K < T <= Ti (ice); mixed phase, colder than 60 K (e_i approaches the float32 denormals,
+// e_w overflows below 32.19 K), hotter than 10^4 K and NaN take the literal expression behind ONE divergent region.
+__device__ __forceinline__ float esat_mixed_f32(float ta) {
+#ifdef PGW_ESAT_F32_LITERAL                                      // A/B knob: round 2's form
+    return esat_mixed_f32_literal(ta);
+#endif
+    const float T0 = 273.16f, Ti = 250.16f;
+    const bool warm = (ta >= T0);
+    const float a3 = warm ? 17.502f : 22.587f;
+    const float a4 = warm ? 32.19f : -0.7f;
+    float e1 = 611.21f * pgw_expf_core(div_ns_f32(a3 * (ta - T0), ta - a4));
+    if (__builtin_expect(!((warm && ta < 1.0e4f) || (ta <= Ti && ta > 60.0f)), 0)) e1 = esat_mixed_f32_literal(no_speculate_f(ta));
+    return e1;
+}
+// hus float32, pa float64 (ak/bk are float64): hus*pa is float64, the denominator CON_MW_MD + 0.378*hus float32 (:63).
+// The two float64 quotients through div_ns like q_to_e / q_to_rh above (divisors of known range: 0.622 + 0.378 q, e_sat).
+__device__ __forceinline__ double q_to_rh_f32_literal(float hus, double pa, float ta);
 __device__ __forceinline__ double q_to_rh_f32(float hus, double pa, float ta) {
+#ifdef PGW_ESAT_F32_LITERAL
+    return q_to_rh_f32_literal(hus, pa, ta);
+#endif
+    const double vapp = div_ns((double)hus * pa, (double)(0.622f + 0.378f * hus));
+    return div_ns(vapp, (double)esat_mixed_f32(ta)) * 100;
+}
+__device__ __forceinline__ double q_to_rh_f32_literal(float hus, double pa, float ta) {
     const double vapp = (double)hus * pa / (double)(0.622f + 0.378f * hus);
-    return (vapp / (double)esat_mixed_f32(ta)) * 100;
+    return (vapp / (double)esat_mixed_f32_literal(ta)) * 100;
 }
 
 __device__ __forceinline__ double div_by_100(double x) { return SharedDivisor(100.0, 0.01).divide(x); }

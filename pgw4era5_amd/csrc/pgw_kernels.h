@@ -1573,11 +1573,20 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
             b_hi = is_sfc(ih) ? sfb : tl(sHur, hb1, ha1);
             ci1 = i1;
         };
+        // plain-axis bracket (ci2, ci2 + 1): its lower abscissa and the reciprocal of its ln-pressure interval, taken when the
+        // bracket changes instead of at every level (2 LDS reads, v_rcp_f64 and 4 FMAs per level less: 1.60 -> 1.55 ms same
+        // box).  float32 storage only: the float64 instantiation sits at its 3-wave register budget (164 of 168 VGPRs; with
+        // the six more live registers it spills) and its time is its bytes.
+        double px1 = 0.0;
+        SharedDivisor by_Dp(1.0, 1.0);
+        constexpr bool HOIST_DP = (sizeof(T) == 4);
+        auto plain_bracket = [&](int i1, int ih) { if (HOIST_DP) { px1 = s_lnp[i1]; by_Dp = SharedDivisor(s_lnp[ih] - px1); } };
         auto fetch2 = [&](int i1) {
             if (ci2 == i1) return;
             const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
             const O oh = off_of(ih);
             const bool seq = (ci2 + 1 == i1);
+            plain_bracket(i1, ih);
             T hb0 = ld_off(sUa.b, oh), hb1 = ld_off(sVa.b, oh), ha0 = 0, ha1 = 0, lb0 = 0, lb1 = 0, la0 = 0, la1 = 0;
             if (LERP) { ha0 = ld_off(sUa.a, oh); ha1 = ld_off(sVa.a, oh); }
             if (!seq) {
@@ -1600,6 +1609,7 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
             T b0 = ld_off(sTa.b, oh), b1 = ld_off(sHur.b, oh), b2 = ld_off(sUa.b, oh), b3 = ld_off(sVa.b, oh);
             T a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             if (LERP) { a0 = ld_off(sTa.a, oh); a1 = ld_off(sHur.a, oh); a2 = ld_off(sUa.a, oh); a3 = ld_off(sVa.a, oh); }
+            plain_bracket(i1, ih);
             a_lo = a_hi; b_lo = b_hi; c_lo = c_hi; d_lo = d_hi;
             a_hi = is_sfc(ih) ? sfa : tl(sTa, b0, a0);
             b_hi = is_sfc(ih) ? sfb : tl(sHur, b1, a1);
@@ -1607,12 +1617,12 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
             d_hi = tl(sVa, b3, a3);
             ci1 = ci2 = i1;
         };
-        int j1 = 0, j2 = 0;
-        double xprev = -__builtin_inf();
         // y_hi - y_lo of the column interpolation (functions.py:575-578): numba takes it in the delta's dtype - float64
         // after a time interpolation, the file's float32 when the instant is a record (REF && !LERP)
         auto ydiff = [](double hi, double lo) -> double {
             return (REF && !LERP) ? (double)((float)hi - (float)lo) : hi - lo; };
+        int j1 = 0, j2 = 0;
+        double xprev = -__builtin_inf();
         // ---- level loop, chunks of U levels with the next chunk's 4*U rows in flight
         T nT[U], nQ[U], nU[U], nV[U];                 // prefetched rows stay in the storage type until they are used
 #pragma unroll
@@ -1657,11 +1667,13 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
                     if (same_axis) fetch12(p1); else fetch2(p1);
                     dc = c_lo; dd = d_lo;
                     double dxp = 0.0;
-                    SharedDivisor by_Dp(1.0, 1.0);
                     if (p1 != p2) {                                                // :575-578
-                        double x1 = s_lnp[p1], x2 = s_lnp[p2];
-                        dxp = x - x1;
-                        by_Dp = SharedDivisor(x2 - x1);                            // x1 < x < x2: finite, positive
+                        if (HOIST_DP) dxp = x - px1;
+                        else {
+                            double x1 = s_lnp[p1], x2 = s_lnp[p2];
+                            dxp = x - x1;
+                            by_Dp = SharedDivisor(x2 - x1);                        // x1 < x < x2: finite, positive
+                        }
                         dc = c_lo + by_Dp.divide(dxp * ydiff(c_hi, c_lo));
                         dd = d_lo + by_Dp.divide(dxp * ydiff(d_hi, d_lo));
                     }
@@ -1706,7 +1718,7 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
                     double hur_pgw = rh_era + db;
                     QST2(oT, o, (TO)ta_pgw);
                     double e_pgw = rh_to_e(hur_pgw, ta_pgw);                       // functions.py:123
-                    if (l < n_pure) QST(oQ, o, (TO)e_to_q(e_pgw, pa));             // pa == akm[l] for every finite ps
+                    if (l < n_pure) QST(oQ, o, (TO)e_to_q_ns(e_pgw, pa));          // pa == akm[l] for every finite ps
                     else QST2(oE, o, (TO)e_pgw);
                     if (oHur) st_off(oHur, o, (TO)hur_pgw);
                 }
@@ -2615,6 +2627,20 @@ __global__ void k_test_log(long long n, const double *__restrict__ in, double *_
 __global__ void k_test_exp(long long n, const double *__restrict__ in, double *__restrict__ out, double *__restrict__ ref) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { out[i] = pgw_exp(in[i]); ref[i] = exp(in[i]); }
+}
+
+// RELHUM of a float32 ERA state in reference-dtype mode (diagnostic entry pgw_test_rh_f32): the fast form the quad kernel
+// uses and the literal expression, side by side
+__global__ void k_test_rh_f32(long long n, const float *__restrict__ hus, const double *__restrict__ pa,
+                              const float *__restrict__ ta, double *__restrict__ out, double *__restrict__ lit,
+                              float *__restrict__ es, float *__restrict__ es_lit) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        out[i] = q_to_rh_f32(hus[i], pa[i], ta[i]);
+        lit[i] = q_to_rh_f32_literal(hus[i], pa[i], ta[i]);
+        es[i] = esat_mixed_f32(ta[i]);
+        es_lit[i] = esat_mixed_f32_literal(ta[i]);
+    }
 }
 
 // SharedDivisor over arrays (diagnostic entry pgw_test_shared_div; tests compare it with IEEE division)

@@ -1324,6 +1324,53 @@ def test_shared_divisor_is_ieee_division():
     np.testing.assert_array_equal(got, want)          # equal doubles = equal bits, up to the sign of a zero quotient and NaN payloads
 
 
+def test_reference_mode_esat_f32_fast_path_is_the_literal_expression():
+    """Reference-dtype mode, RELHUM of the float32 ERA state (step_03:91-94 through functions.py:58-116 on float32 arrays):
+    the quad kernel evaluates ONE phase of e_sat (alpha in {0, 1} makes the other term an exact zero), with scale-free
+    float32 / float64 divisions and the library's expf arithmetic without its range selects.  It must give the bits of the
+    expression as written - both phases, IEEE divisions, expf() - for every float32 temperature (the mixed range, below
+    60 K, NaN and infinities take the literal code), and the literal e_sat must be numpy's float32 evaluation to 4 ulp
+    (the device expf against numpy's SIMD float32 exp, each within a few ulp of the exact value, and alpha's weights in
+    the mixed range; tests/golden/ref_leaf_f32_vectors.npz pins the dtype flow itself)."""
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(77)
+    n = 1 << 21
+    ta = rng.uniform(150.0, 340.0, n).astype(np.float32)
+    ta[:200000] = rng.uniform(249.0, 274.5, 200000).astype(np.float32)             # around both phase limits
+    edge = np.array([273.16, 250.16, 60.0, 32.19, -0.7, 0.0, 1e4, 3e38, np.inf, -np.inf, np.nan, 40.0, 59.999, 60.001],
+                    np.float32)
+    edge = np.concatenate([edge, np.nextafter(edge, np.float32(np.inf)), np.nextafter(edge, np.float32(-np.inf))])
+    ta[200000:200000 + edge.size] = edge
+    ta[300000:310000] = rng.uniform(-50.0, 70.0, 10000).astype(np.float32)         # unphysically cold
+    hus = rng.uniform(0.0, 0.03, n).astype(np.float32)
+    hus[:16] = [0.0, 1e-7, 1e-30, 0.5, 1.0, np.nan, -1e-5, 3e-6, 0.02, 0.03, 1e-3, 1e-4, 1e-5, 1e-6, 0.01, 0.005]
+    pa = rng.uniform(1.0, 1.08e5, n)
+    d_ta, d_hus, d_pa = ctx.to_device(ta, np.float32), ctx.to_device(hus, np.float32), ctx.to_device(pa)
+    out, lit = ctx.empty((n,), np.float64), ctx.empty((n,), np.float64)
+    es, es_lit = ctx.empty((n,), np.float32), ctx.empty((n,), np.float32)
+    ctx._check(ctx.lib.pgw_test_rh_f32(ctx.handle, n, d_hus.ptr, d_pa.ptr, d_ta.ptr, out.ptr, lit.ptr, es.ptr, es_lit.ptr))
+    g_es, w_es = es.numpy(), es_lit.numpy()
+    np.testing.assert_array_equal(g_es.view(np.uint32)[~np.isnan(w_es)], w_es.view(np.uint32)[~np.isnan(w_es)])
+    assert np.isnan(g_es[np.isnan(w_es)]).all()
+    phys = np.isfinite(ta) & (ta > 60.0)
+    got, want = out.numpy(), lit.numpy()
+    np.testing.assert_array_equal(got[phys], want[phys])                           # NaN == NaN positions included
+    # the literal e_sat against numpy's float32 evaluation of functions.py:74-105
+    with np.errstate(all='ignore'):
+        t = ta[phys]
+        f32 = np.float32
+        ew = f32(611.21) * np.exp(f32(17.502) * (t - f32(273.16)) / (t - f32(32.19)))
+        ei = f32(611.21) * np.exp(f32(22.587) * (t - f32(273.16)) / (t - f32(-0.7)))
+        alpha = np.where(t >= f32(273.16), f32(1), np.where(t <= f32(250.16), f32(0), ((t - f32(250.16)) / f32(23.0)) ** 2)).astype(f32)
+        ref = alpha * ew + (f32(1) - alpha) * ei
+    ok = np.isfinite(ref) & (ref > 1e-30)
+    ulp = np.abs(w_es[phys][ok].astype(np.float64) - ref[ok].astype(np.float64)) / np.spacing(ref[ok]).astype(np.float64)
+    assert ok.sum() > 2000000 and ulp.max() <= 4.0, ulp.max()
+    for x in (d_ta, d_hus, d_pa, out, lit, es, es_lit):
+        x.free()
+
+
 def test_device_exp_is_library_exp():
     """pgw_exp (explicit-FMA restatement of the device library's exp, used by every e_sat evaluation) gives the
     library's bits over the arguments of the path and far beyond, incl. overflow / underflow / NaN / inf, and is
