@@ -140,6 +140,231 @@ def kernel_bytes(name, N, S, ncol, s, info):
     return 0
 
 
+def gather_objects(dist, obj, world):
+    """list of every rank's `obj` (one-element list at N = 1)"""
+    if dist is None:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def scratch_ok(path, need_bytes):
+    """(ok, note): does `path` have room for `need_bytes` of files without endangering the host?  Twice the bytes free on
+    the file system; on a memory-backed file system (tmpfs / ramfs) also a third of MemAvailable at most."""
+    import shutil
+    os.makedirs(path, exist_ok=True)
+    free = shutil.disk_usage(path).free
+    if free < 2 * need_bytes:
+        return False, 'scratch %s has %.0f GB free, the leg writes %.0f GB' % (path, free / 1e9, need_bytes / 1e9)
+    fstype, best = None, ''
+    try:
+        real = os.path.realpath(path)
+        for ln in open('/proc/mounts'):
+            f = ln.split()
+            if len(f) >= 3 and (real == f[1] or real.startswith(f[1].rstrip('/') + '/')) and len(f[1]) >= len(best):
+                best, fstype = f[1], f[2]
+        if fstype in ('tmpfs', 'ramfs'):
+            avail = 0
+            for ln in open('/proc/meminfo'):
+                if ln.startswith('MemAvailable:'):
+                    avail = int(ln.split()[1]) * 1024
+            if need_bytes > avail / 3:
+                return False, 'scratch %s is %s: %.0f GB of files against %.0f GB of available memory' % (path, fstype, need_bytes / 1e9, avail / 1e9)
+    except OSError:
+        pass
+    return True, fstype
+
+
+def cli_leg_all_ranks(a, rank, world, dist, barrier, files_per_rank=3):
+    """End to end through the step_03 command line with ALL ranks at once, every rank writing into the same scratch
+    directory: rank 0 writes two synthetic float32 0.25 deg L137 ERA5 files + the delta directory and links them under
+    `files_per_rank x world` hourly names; every rank then runs `step_03_apply_to_era._cli(... -p W)` IN THIS PROCESS -
+    under torch.distributed.run that is parallel.IterMP._run_distributed on the existing process group: file i -> rank
+    i mod W, each rank the five-stage pipeline (pread -> h2d -> kernels -> d2h -> pwrite) on its GPU.  Reported: wall seconds
+    per file over all ranks (slowest rank, start-up = delta upload + pinning included), the steady-state rate from the
+    output files' modification times, for the reference's float64 T, QV, U, V and for settings.f32_out_dtype = 'float32'.
+    This is what shared host memory bandwidth, PCIe and the scratch file system can make worse than 1 / N (reference
+    `-p N`: parallel.py:18-32, step_03_apply_to_era.py:590-638)."""
+    import glob
+    import shutil
+    import tempfile
+    import numpy as np
+    from pgw4era5_amd import synthetic, settings as S, step_03_apply_to_era as s3
+    nfiles = files_per_rank * world
+    one_in = 4 * a.nlat * a.nlon * a.nlev * 4 + 20 * a.nlat * a.nlon * 4
+    res = {'files': nfiles, 'ranks': world}
+    plan = None
+    if rank == 0:
+        base = a.e2e_dir or tempfile.mkdtemp(prefix='pgw_e2e_ranks_')
+        ok64, note64 = scratch_ok(base, 2 * one_in + nfiles * 2 * one_in)
+        ok32, note32 = scratch_ok(base, 2 * one_in + nfiles * one_in)
+        plan = {'dir': base, 'modes': ([('float64', None)] if ok64 else [('float64', note64)]) +
+                ([('float32', None)] if ok32 else [('float32', note32)])}
+        if ok32:
+            try:
+                case = synthetic.make_case(a.nlat, a.nlon, a.nlev, seed=1, dtype=np.float32)
+                first = dt.datetime(2006, 8, 2, 0)
+                real = []
+                for i in range(min(2, nfiles)):
+                    case['target_dt'] = first + dt.timedelta(hours=i)
+                    real.append(synthetic.write_case_files(case, os.path.join(base, 'era'), os.path.join(base, 'deltas')))
+                for i in range(len(real), nfiles):       # further hourly names: links to the two files (reads are 0.05 s of a file's 0.3)
+                    os.symlink(real[i % len(real)], os.path.join(base, 'era', S.era5_file_name_base.format(first + dt.timedelta(hours=i))))
+                del case
+            except Exception as e:      # noqa: BLE001
+                plan = {'error': '%s: %s' % (type(e).__name__, e)}
+    plan = gather_objects(dist, plan, world)[0]
+    if plan is None or 'error' in plan:
+        return {'error': (plan or {}).get('error', 'no plan')}
+    base = plan['dir']
+    first = dt.datetime(2006, 8, 2, 0)
+    last = first + dt.timedelta(hours=nfiles - 1)
+    old_debug, old_out = S.i_debug, S.f32_out_dtype
+    S.i_debug = 0
+    try:
+        for mode, why_not in plan['modes']:
+            key = 'float64_out' if mode == 'float64' else 'float32_out'
+            if why_not is not None:
+                res[key] = {'skipped': why_not}
+                continue
+            S.f32_out_dtype = mode
+            outdir = os.path.join(base, 'out_' + mode)
+            argv = ['-i', os.path.join(base, 'era'), '-o', outdir, '-d', os.path.join(base, 'deltas'),
+                    '-f', first.strftime('%Y%m%d%H'), '-l', last.strftime('%Y%m%d%H'), '-H', '1', '-p', str(world), '-t']
+            err = None
+            barrier()
+            t0 = time.time()
+            try:
+                n_iter = s3._cli(argv)
+            except Exception as e:      # noqa: BLE001
+                err, n_iter = '%s: %s' % (type(e).__name__, e), None
+            barrier()
+            wall = time.time() - t0
+            errs = [e for e in gather_objects(dist, err, world) if e]
+            if rank == 0:
+                if errs:
+                    res[key] = {'error': errs[0]}
+                else:
+                    done = sorted(os.path.getmtime(f) for f in glob.glob(os.path.join(outdir, '*.nc')))
+                    k = min(world, len(done) - 1)       # the first file of every rank: pipeline fill, delta upload, pinning
+                    steady = (done[-1] - done[k - 1]) / (len(done) - k) if (k >= 1 and len(done) > k and done[-1] > done[k - 1]) else None
+                    size = os.path.getsize(sorted(glob.glob(os.path.join(outdir, '*.nc')))[0])
+                    res[key] = dict(n_iter=sorted(set(n_iter)) if n_iter else None, out_file_GB=round(size / 1e9, 3),
+                                    wall_s=round(wall, 2), wall_s_per_file=round(wall / nfiles, 3),
+                                    steady_state_s_per_file=None if steady is None else round(steady, 4),
+                                    files_per_hour_all_ranks=round(3600.0 / (steady if steady else wall / nfiles), 1))
+                shutil.rmtree(outdir, ignore_errors=True)
+            barrier()
+    finally:
+        S.i_debug, S.f32_out_dtype = old_debug, old_out
+        if rank == 0 and not a.e2e_dir:
+            shutil.rmtree(base, ignore_errors=True)
+        elif rank == 0:
+            for sub in ('era', 'deltas'):
+                shutil.rmtree(os.path.join(base, sub), ignore_errors=True)
+    return res
+
+
+def pcie_f32_leg(ctx, case, coeffs, np):
+    """The pipelined PCIe-inclusive rate of this rank for a float32 file in reference-dtype mode (2.3 GB in, 4.55 GB out)
+    and with settings.f32_out_dtype = 'float32' (2.3 GB out) - the leg `extras.f32_storage` carries at N = 1."""
+    import ctypes as C
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    f32 = np.float32
+    era32 = {k: (v.astype(f32) if isinstance(v, np.ndarray) and v.ndim >= 3 else v) for k, v in case['era'].items()}
+    d32 = {k: v.astype(f32) for k, v in case['deltas'].items()}
+    deltas = s3.DeltaSet(ctx, d32, case['delta_times'], case['plev'], f32)
+    era = s3._upload_era(ctx, era32, f32)
+    names = ('T', 'QV', 'U', 'V')
+    n4 = era['T'].nbytes
+    hp = []
+    res = {}
+    try:
+        for k in names:
+            p = C.c_void_p()
+            ctx._check(ctx.lib.pgw_host_alloc(ctx.handle, n4, C.byref(p)))
+            C.memmove(p, era32[k].ctypes.data, n4)
+            hp.append(p)
+        del era32, d32
+        res['float64_out'] = pcie_pipelined(ctx, era, coeffs, deltas, case, True, names, hp, n4)
+        res['float32_out'] = pcie_pipelined(ctx, era, coeffs, deltas, case, True, names, hp, n4, narrow=True)
+    finally:
+        for p in hp:
+            ctx.lib.pgw_host_free(ctx.handle, p)
+        for v in list(era.values()) + list(deltas.dev.values()) + [deltas.ts_clim]:
+            if v is not None:
+                v.free()
+    return res
+
+
+def per_rank_object(aff_all, pcie_all, cli_all):
+    """What an N-rank line reports beside the HBM-resident `value` - the legs that can fail to scale: every rank's host
+    placement, every rank's pipelined PCIe-inclusive rate for a float32 file in reference-dtype mode (all ranks measuring at
+    once), and the end-to-end command-line rate with all ranks writing into one scratch directory."""
+    out = {'affinity': aff_all,
+           'affinity_disjoint': None,
+           'pcie_inclusive_f32_reference': None, 'end_to_end_cli_all_ranks': cli_all}
+    sets = []
+    try:
+        from pgw4era5_amd.parallel import parse_cpulist
+        sets = [parse_cpulist(x['cpus']) for x in aff_all if x and x.get('bound')]
+        if len(sets) == len(aff_all) and sets:
+            out['affinity_disjoint'] = all(not (sets[i] & sets[j]) for i in range(len(sets)) for j in range(i))
+    except Exception:                              # noqa: BLE001
+        pass
+    if any(p for p in pcie_all):
+        legs = {}
+        for key in ('float64_out', 'float32_out'):
+            vals = [(p or {}).get(key) if isinstance(p, dict) else None for p in pcie_all]
+            ms = [v.get('ms_per_file') if isinstance(v, dict) else None for v in vals]
+            good = [m for m in ms if m]
+            legs[key] = {'ms_per_file_by_rank': ms,
+                         'files_per_hour_all_ranks': round(sum(3.6e6 / m for m in good), 1) if good else None,
+                         'GB_in': next((v.get('GB_in') for v in vals if isinstance(v, dict) and 'GB_in' in v), None),
+                         'GB_out': next((v.get('GB_out') for v in vals if isinstance(v, dict) and 'GB_out' in v), None),
+                         'errors': [v.get('error') for v in vals if isinstance(v, dict) and 'error' in v] or None}
+        errs = [p['error'] for p in pcie_all if isinstance(p, dict) and 'error' in p]
+        if errs:
+            legs['errors'] = errs
+        out['pcie_inclusive_f32_reference'] = legs
+    return out
+
+
+def roofline_object(dom, kern, a):
+    """The `roofline` object of the line for kernel `dom` of a run described by `a` (storage, f32_mode, shape): HIP-event
+    figure of this run, PMC traffic and rocprofv3 average from the committed summaries of the same command."""
+    traffic, tsrc = pmc_traffic(dom, a)
+    roof = dict(bound='hbm', kernel=dom, achieved=kern[dom]['GBps'], peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_unit='GB/launch',
+                traffic_source=tsrc, avg_launch_ms=kern[dom]['avg_ms'],
+                algorithmic_GB_per_launch=kern[dom]['algo_GB'],
+                timing='HIP events on the launching stream, this run (frac); frac_rocprof = the same algorithmic bytes over '
+                       'the committed rocprofv3 --kernel-trace average of the timed launches')
+    roof.update(rocprof_frac(dom, a, kern[dom]['algo_GB']))
+    valu = pmc_valu(dom, a, kern[dom]['avg_ms'])
+    if valu:
+        roof['valu_fp64'] = valu
+    return roof
+
+
+def kernel_table(prof, N, S, ncol, s, kinfo):
+    """per-kernel launches / average ms / algorithmic GB / GB/s from the context's HIP-event profile"""
+    kern = {}
+    for k, (cnt, ms) in prof.items():
+        if cnt == 0:
+            continue
+        avg_ms = ms / cnt
+        b = kernel_bytes(k, N, S, ncol, s, kinfo)
+        kern[k] = dict(launches=cnt, avg_ms=round(avg_ms, 4), total_ms=round(ms, 3),
+                       algo_GB=round(b / 1e9, 4), GBps=round(b / 1e9 / (avg_ms / 1e3), 1) if b else None)
+    return kern
+
+
+FILE_KERNELS = ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'ps_loop_multi', 'finalize',
+                'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q', 'pressure', 'time_lerp')
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
@@ -173,6 +398,14 @@ def main(argv=None):
             if not a.dry_run:
                 local = local % max(torch.cuda.device_count(), 1)
 
+    # host placement of this rank: its GPU's NUMA node, a CPU set disjoint from the other ranks' (before any pinned
+    # allocation and before the stage threads exist)
+    from pgw4era5_amd.parallel import bind_rank_to_numa
+    try:
+        affinity = bind_rank_to_numa(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
+    except Exception as e:                  # noqa: BLE001 - placement is an optimisation, never a reason to lose the line
+        affinity = {'bound': False, 'note': '%s: %s' % (type(e).__name__, e)}
+
     def reduce(x, op):
         """float all-reduce over the ranks (RCCL on device memory, gloo on host memory)"""
         if dist is None:
@@ -187,11 +420,13 @@ def main(argv=None):
             dist.barrier()
         seen = int(round(reduce(1.0, 'SUM')))
         el = reduce(1e-3 * (rank + 1), 'MAX')
+        aff_all = gather_objects(dist, affinity, world)
+        per_rank = per_rank_object(aff_all, [None] * world, None)
         if rank == 0:
             print(json.dumps({'metric': 'ERA5 files/hour (0.25deg L137), step_03 hot path, inputs resident in HBM',
                               'value': None, 'unit': 'files/hour', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                               'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                              'dtype': 'f64', 'data': 'synthetic', 'dry_run': True,
+                              'dtype': 'f64', 'data': 'synthetic', 'dry_run': True, 'per_rank': per_rank,
                               'collective': {'backend': backend, 'ranks_counted_by_all_reduce': seen, 'max_reduced': el},
                               'config': {'workload': 'dry run: launch path only, no GPU work'}}), flush=True)
         if dist is not None:
@@ -252,22 +487,43 @@ def main(argv=None):
         infos.append(info)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = {k: ctx.profile_get(k) for k in ('quad_delta', 'thermo_delta', 'wind_delta', 'phi_ref_hybrid', 'adjust_ps_step', 'ps_loop_multi', 'finalize',
-                                            'surface', 'integ_geopot', 'vert_interp_delta', 'q_to_rh', 'rh_to_q',
-                                            'pressure', 'time_lerp')}
+    prof = {k: ctx.profile_get(k) for k in FILE_KERNELS}
     solo = (rank == 0 and world == 1)
     micro = microbench(ctx, era, coeffs, a, np) if solo else {}       # N = 1 only: keeps multi-rank runs short
+    for k, v in micro.items():
+        # beside the HIP-event figure of this run: the fraction from the committed rocprofv3 trace of the same command.
+        # They differ most for `pressure`, a pure-write kernel whose event time depends on what the kernel before it left
+        # in the caches (0.33-0.39 ms); the rocprofv3 average is the figure to quote.
+        rp = rocprof_frac(k, a, v['algo_GB'])
+        if rp:
+            v['frac_rocprof'] = rp['frac_rocprof']
+            v['rocprof_timed_avg_launch_ms'] = rp['rocprof_timed_avg_launch_ms']
+            v['rocprof_source'] = rp['rocprof_source']
     overlap = overlap_region(local, era, coeffs, deltas, stamps[a.warmup:], a, ref) if (solo and a.overlap_streams > 1) else None
     ctx.profile(False)
     latency = None
     bk_host = case['era']['bk']
+    pcie_rank, cli_all = None, None
     if dist is not None:                            # N > 1 (and the one-rank RCCL rehearsal, PGW_BENCH_FORCE_DIST=1)
         if world > 1:
+            if not a.no_extras:
+                try:                                # every rank at once: PCIe and host memory bandwidth are shared
+                    barrier()
+                    pcie_rank = pcie_f32_leg(ctx, case, coeffs, np)
+                except Exception as e:              # noqa: BLE001
+                    pcie_rank = {'error': '%s: %s' % (type(e).__name__, e)}
             case = None                             # host copy of this rank's file (~15 GB): free it before the shared file is built
         try:
             latency = latency_mode(ctx, a, rank, world, dist, backend, dtype, ref)
         except Exception as e:                      # noqa: BLE001 - a side measurement, never costs the headline line
             latency = {'error': '%s: %s' % (type(e).__name__, e)}
+    if dist is not None and world > 1 and not a.no_extras and a.e2e_files > 0:
+        try:
+            cli_all = cli_leg_all_ranks(a, rank, world, dist, barrier)
+        except Exception as e:                      # noqa: BLE001
+            cli_all = {'error': '%s: %s' % (type(e).__name__, e)}
+    aff_all = gather_objects(dist, affinity, world)
+    pcie_all = gather_objects(dist, pcie_rank, world)
     elapsed = reduce(elapsed, 'MAX')
     ranks_seen = int(round(reduce(1.0, 'SUM')))
     iters_min = int(round(reduce(float(min(i['n_iter'] for i in infos)), 'MIN')))
@@ -286,30 +542,13 @@ def main(argv=None):
         launches_multi = prof['ps_loop_multi'][0]
         kinfo = dict(levels_per_launch=lv_per_launch, qv_done_levels=n_pure if quad else 0, so=so,
                      passes_per_launch=(sum(i.get('passes_launched', 0) for i in infos) / launches_multi) if launches_multi else 1.0)
-        kern = {}
-        for k, (cnt, ms) in prof.items():
-            if cnt == 0:
-                continue
-            avg_ms = ms / cnt
-            b = kernel_bytes(k, N, S, ncol, s, kinfo)
-            kern[k] = dict(launches=cnt, avg_ms=round(avg_ms, 4), total_ms=round(ms, 3),
-                           algo_GB=round(b / 1e9, 4), GBps=round(b / 1e9 / (avg_ms / 1e3), 1) if b else None)
+        kern = kernel_table(prof, N, S, ncol, s, kinfo)
         cand = [k for k in kern if kern[k]['GBps']]
         if not cand:                       # PGW_BENCH_NOPROF: no per-kernel timings
             print(json.dumps({'ms_per_step': round(elapsed / a.steps * 1e3, 3), 'note': 'launch profiling disabled'}), flush=True)
             return 0
         dom = max(cand, key=lambda k: kern[k]['total_ms'])
-        traffic, tsrc = pmc_traffic(dom, a)
-        roof = dict(bound='hbm', kernel=dom, achieved=kern[dom]['GBps'], peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_unit='GB/launch',
-                    traffic_source=tsrc, avg_launch_ms=kern[dom]['avg_ms'],
-                    algorithmic_GB_per_launch=kern[dom]['algo_GB'],
-                    timing='HIP events on the launching stream, this run (frac); frac_rocprof = the same algorithmic bytes over '
-                           'the committed rocprofv3 --kernel-trace average of the timed launches')
-        roof.update(rocprof_frac(dom, a, kern[dom]['algo_GB']))
-        valu = pmc_valu(dom, a, kern[dom]['avg_ms'])
-        if valu:
-            roof['valu_fp64'] = valu
+        roof = roofline_object(dom, kern, a)
         files = a.steps * world
         res = {
             'metric': 'ERA5 files/hour (0.25deg L137), step_03 hot path, inputs resident in HBM',
@@ -345,6 +584,16 @@ def main(argv=None):
                 res['extras'] = extras(ctx, case, era, coeffs, deltas, a, np)
             except Exception as e:          # noqa: BLE001 - side measurements never cost the headline line
                 res['extras'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        f32s = (res['extras'] or {}).get('f32_storage') or {}
+        if world == 1 and res['extras']:            # the same legs, measured by `extras` at N = 1
+            ex = res['extras']
+            pcie_all = [{'float64_out': f32s.get('pcie_inclusive_reference'), 'float32_out': f32s.get('pcie_inclusive_reference_f32_out')}]
+            cli_all = {'files': a.e2e_files, 'ranks': 1, 'float64_out': ex.get('end_to_end_cli'), 'float32_out': ex.get('end_to_end_cli_f32_out')}
+        res['per_rank'] = per_rank_object(aff_all, pcie_all, cli_all)
+        if 'roofline' in f32s.get('reference', {}):
+            # float32 files in reference-dtype mode - what real ERA5 files run by default - beside the float64 object
+            res['roofline_f32ref'] = dict(f32s['reference']['roofline'], ms_per_file=f32s['reference']['ms_per_file'],
+                                          iterations=f32s['reference']['iterations'])
         if cpu is not None:
             res['cpu_baseline'] = cpu
         assert res['n_gpus'] == a.gpus == ranks_seen, (res['n_gpus'], a.gpus, ranks_seen)
@@ -560,6 +809,13 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
         del r, oc
     except Exception as e:      # noqa: BLE001
         out['gauss_interp_tos_12_months'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    # the reference's two other operating modes on the same resident file (settings.p_ref_inp = None: step_03:219-253;
+    # settings.i_reinterp = 1: step_03:202-216, 330-343), HBM-resident like `value`
+    for key, which in (('local_p_ref', 'local'), ('i_reinterp', 'reinterp')):
+        try:
+            out[key] = mode_leg(ctx, era, coeffs, deltas, case, a, which)
+        except Exception as e:      # noqa: BLE001
+            out[key] = {'error': '%s: %s' % (type(e).__name__, e)}
     # float32 storage (what real ERA5 files hold), HBM-resident like `value`: both modes of settings.f32_file_mode
     if dt == np.float64:
         try:
@@ -579,27 +835,90 @@ def extras(ctx, case, era, coeffs, deltas, a, np):
     return out
 
 
-def pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4, files=8):
+def mode_leg(ctx, era, coeffs, deltas, case, a, which, files=4, warmup=2):
+    """ms per file, passes and the per-kernel HIP-event table (launches and ms per file, algorithmic GB per launch where
+    bench.py defines them) of the step_03 path in another of the reference's modes: which = 'local' (p_ref_inp = None, the
+    LOCAL form of the multi-pass loop kernel) or 'reinterp' (i_reinterp = 1: ta / hur and their deltas re-interpolated onto
+    the current levels in every pass, ua / va once at the end)."""
+    from pgw4era5_amd import _lib, step_03_apply_to_era as s3
+    s = era['T'].dtype.itemsize
+    nt, N, nlat, nlon = era['T'].shape
+    ncol, S = nlat * nlon, len(case['plev'])
+    outb = {}
+
+    def one(i):
+        stamp = case['target_dt'] + dt_mod.timedelta(hours=i)
+        if which == 'local':
+            return s3.process_file_device(ctx, era, coeffs, deltas, stamp, True, p_ref='local', out=outb)[1]
+        return s3.process_file_device_reinterp(ctx, era, coeffs, deltas, stamp, True, out=outb)[1]
+    ctx.profile(True)
+    for i in range(warmup):
+        one(i)
+    ctx.sync()
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    infos = [one(warmup + i) for i in range(files)]
+    ctx.sync()
+    el = (time.perf_counter() - t0) / files
+    prof = {k: ctx.profile_get(k) for k in _lib.KERNEL_IDS}
+    ctx.profile(False); ctx.profile_reset()
+    for v in outb.values():
+        v.free()
+    passes = sum(i['n_iter'] for i in infos)
+    bk = coeffs['bk']
+    n_pure = 0
+    while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
+        n_pure += 1
+    touched = sum(i.get('levels_touched', 0) for i in infos)
+    kinfo = dict(so=s, levels_per_launch=touched / max(passes, 1), qv_done_levels=n_pure if ctx.get_option('quad') != 0 else 0,
+                 passes_per_launch=(sum(i.get('passes_launched', 0) for i in infos) / prof['ps_loop_multi'][0])
+                 if prof['ps_loop_multi'][0] else 1.0)
+    kern = {}
+    for k, (cnt, ms) in prof.items():
+        if not cnt:
+            continue
+        # i_reinterp: the pair kernel (k_reinterp_pair: two ERA fields + two deltas onto the current levels) runs under the
+        # vert_interp_delta id: 2 fields in, 2 out, 2 records x S x 2 variables, ~6 2-D fields
+        if which == 'reinterp' and k == 'vert_interp_delta':
+            b = (4 * N + 4 * S + 6) * ncol * s
+        elif k in ('adjust_ps_step', 'ps_loop_multi', 'phi_ref_hybrid') and not touched:
+            b = 0                                # levels read per pass not reported by this path: no byte figure
+        else:
+            b = kernel_bytes(k, N, S, ncol, s, kinfo)
+        kern[k] = dict(launches_per_file=round(cnt / files, 2), ms_per_file=round(ms / files, 3), avg_launch_ms=round(ms / cnt, 4),
+                       algo_GB_per_launch=round(b / 1e9, 3) if b else None,
+                       GBps=round(b / 1e9 / (ms / cnt / 1e3), 1) if b else None)
+    n_iter = [i['n_iter'] for i in infos]
+    return dict(ms_per_file=round(el * 1e3, 3), files_per_hour=round(3600.0 / el, 1), files=files,
+                iterations=n_iter[0] if len(set(n_iter)) == 1 else n_iter, kernels=kern)
+
+
+def pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4, files=8, narrow=False):
     """The same host-to-host work as `pcie_inclusive`, organised like the file driver (step_03_apply_to_era.py stages):
     uploads on the 'h2d' stream, kernels on the context's stream, downloads on the 'd2h' stream, two device buffer sets
     each way, one host thread per stage - so the upload of file i+1 and the download of file i-1 run during the kernels of
     file i and PCIe carries both directions at once.  ms per file = wall time of `files` files / files (fill and drain
-    included)."""
+    included).  n4 = bytes of one input field; an output field is downloaded whole (twice n4 in reference-dtype mode:
+    float64 T, QV, U, V of a float32 file), or, with narrow (settings.f32_out_dtype = 'float32'), after
+    pgw_narrow_f64_f32 on the GPU (n4 again)."""
     import ctypes as C
     import queue
     import threading
+    import numpy as np
     from pgw4era5_amd import step_03_apply_to_era as s3
     up, dn = ctx.side('h2d'), ctx.side('d2h')
     second = {k: (ctx.empty(v.shape, v.dtype) if k in names else v) for k, v in era.items()}   # small fields: shared, read-only
     in_sets, out_sets = [era, second], [{}, {}]
-    hout = []
-    for _ in range(4):
-        p = C.c_void_p()
-        ctx._check(ctx.lib.pgw_host_alloc(ctx.handle, n4, C.byref(p)))
-        hout.append(p)
     for o in out_sets:                       # allocate the outputs outside the timed region
         s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=o, ref_dtype=ref)
     ctx.sync()
+    nout = n4 if narrow else out_sets[0][names[0]].nbytes
+    narrowed = [{k: ctx.empty(era[k].shape, np.float32) for k in names} for _ in out_sets] if narrow else None
+    hout = []
+    for _ in range(4):
+        p = C.c_void_p()
+        ctx._check(ctx.lib.pgw_host_alloc(ctx.handle, nout, C.byref(p)))
+        hout.append(p)
     in_free, out_free, q_c, q_d = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
     for i in (0, 1):
         in_free.put(i); out_free.put(i)
@@ -630,6 +949,9 @@ def pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4, files=8):
                 break
             o = out_free.get()
             s3.process_file_device(ctx, in_sets[s], coeffs, deltas, case['target_dt'], True, out=out_sets[o], ref_dtype=ref)
+            if narrow:
+                for k in names:
+                    ctx._check(ctx.lib.pgw_narrow_f64_f32(ctx.handle, out_sets[o][k].size, out_sets[o][k].ptr, narrowed[o][k].ptr, 1))
             ctx.sync()
             in_free.put(s)
             q_d.put(o)
@@ -640,8 +962,9 @@ def pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4, files=8):
             o = q_d.get()
             if o is None:
                 break
+            src = narrowed[o] if narrow else out_sets[o]
             for k, p in zip(names, hout):
-                dn._check(dn.lib.pgw_memcpy_d2h(dn.handle, p, out_sets[o][k].ptr, n4))
+                dn._check(dn.lib.pgw_memcpy_d2h(dn.handle, p, src[k].ptr, nout))
             dn.sync()
             out_free.put(o)
     th = [threading.Thread(target=guard(f)) for f in (uploader, computer, downloader)]
@@ -655,18 +978,26 @@ def pcie_pipelined(ctx, era, coeffs, deltas, case, ref, names, hp, n4, files=8):
         ctx.lib.pgw_host_free(ctx.handle, p)
     for k in names:
         second[k].free()
+        if narrow:
+            for nb in narrowed:
+                nb[k].free()
     for o in out_sets:
         for v in o.values():
             v.free()
     if errs:
         return {'error': errs[0]}
     return dict(ms_per_file=round(el * 1e3, 2), files_per_hour=round(3600.0 / el, 1), files=files,
+                GB_in=round(4 * n4 / 1e9, 3), GB_out=round(4 * nout / 1e9, 3),
                 note='three HIP streams (h2d, kernels, d2h), two device buffer sets each way, one host thread per stage')
 
 
-def f32_storage(ctx, case, coeffs, a, np, steps=5):
-    """The timed region again on a float32 copy of the same file: reference-dtype mode (float64 4-D outputs, the
-    reference's roundings) and float64 arithmetic with float32 outputs."""
+def f32_storage(ctx, case, coeffs, a, np, steps=10, warmup=2):
+    """The timed region again on a float32 copy of the same file - what real ERA5 files are: reference-dtype mode
+    (float64 4-D outputs, the reference's roundings; settings.f32_file_mode default) and float64 arithmetic with float32
+    outputs.  Per mode: ms per file, the per-kernel HIP-event table and the `roofline` object of its dominant kernel
+    (algorithmic bytes of THAT storage layout; PMC traffic / rocprofv3 average from the committed summaries of
+    `bench.py --storage f32 [--f32-mode fast]`)."""
+    import argparse
     from pgw4era5_amd import step_03_apply_to_era as s3
     f32 = np.float32
     era32 = {k: (v.astype(f32) if isinstance(v, np.ndarray) and v.ndim >= 3 else v) for k, v in case['era'].items()}
@@ -674,20 +1005,63 @@ def f32_storage(ctx, case, coeffs, a, np, steps=5):
     deltas = s3.DeltaSet(ctx, d32, case['delta_times'], case['plev'], f32)
     era = s3._upload_era(ctx, era32, f32)
     del era32, d32
+    N, S, ncol = a.nlev, len(case['plev']), a.nlat * a.nlon
+    bk = case['era']['bk']
+    n_pure = 0
+    while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
+        n_pure += 1
     res = {}
     for mode, ref in (('reference', True), ('fast', False)):
-        outb = {}
-        s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=outb, ref_dtype=ref)
+        outb, infos = {}, []
+        ctx.profile(True)
+        for i in range(warmup):
+            s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'], True, out=outb, ref_dtype=ref)
         ctx.sync()
+        ctx.profile_reset()
         t0 = time.perf_counter()
         for i in range(steps):
             _, info = s3.process_file_device(ctx, era, coeffs, deltas, case['target_dt'] + dt_mod.timedelta(hours=i), True,
                                              out=outb, ref_dtype=ref)
+            infos.append(info)
         ctx.sync()
         el = (time.perf_counter() - t0) / steps
-        res[mode] = dict(ms_per_file=round(el * 1e3, 3), files_per_hour=round(3600.0 / el, 1), iterations=info['n_iter'])
+        prof = {k: ctx.profile_get(k) for k in FILE_KERNELS}
+        ctx.profile(False); ctx.profile_reset()
+        passes = sum(i['n_iter'] for i in infos)
+        launches_multi = prof['ps_loop_multi'][0]
+        kinfo = dict(levels_per_launch=sum(i['levels_touched'] for i in infos) / max(passes, 1),
+                     qv_done_levels=n_pure if (not a.full_column and ctx.get_option('quad') != 0) else 0, so=8 if ref else 4,
+                     passes_per_launch=(sum(i.get('passes_launched', 0) for i in infos) / launches_multi) if launches_multi else 1.0)
+        kern = kernel_table(prof, N, S, ncol, 4, kinfo)
+        res[mode] = dict(ms_per_file=round(el * 1e3, 3), files_per_hour=round(3600.0 / el, 1), iterations=info['n_iter'],
+                         files=steps, kernels=kern)
+        cand = [k for k in kern if kern[k]['GBps']]
+        if cand:
+            like = argparse.Namespace(storage='f32', f32_mode=mode, nlat=a.nlat, nlon=a.nlon, nlev=a.nlev)
+            res[mode]['roofline'] = roofline_object(max(cand, key=lambda k: kern[k]['total_ms']), kern, like)
         for v in outb.values():
             v.free()
+    # PCIe-inclusive, pipelined, for a float32 file in reference-dtype mode - the production case: 2.3 GB in, 4.55 GB out
+    # (float64 T, QV, U, V like the reference writes them), and with settings.f32_out_dtype = 'float32' (2.3 GB out)
+    try:
+        import ctypes as C
+        names = ('T', 'QV', 'U', 'V')
+        n4 = era['T'].nbytes
+        hp = []
+        for _ in names:
+            p = C.c_void_p()
+            ctx._check(ctx.lib.pgw_host_alloc(ctx.handle, n4, C.byref(p)))
+            C.memset(p, 0, 64)
+            hp.append(p)
+        for k, p in zip(names, hp):                       # the file's own values (a re-upload must not change the result)
+            ctx._check(ctx.lib.pgw_memcpy_d2h(ctx.handle, p, era[k].ptr, n4))
+        ctx.sync()
+        res['pcie_inclusive_reference'] = pcie_pipelined(ctx, era, coeffs, deltas, case, True, names, hp, n4)
+        res['pcie_inclusive_reference_f32_out'] = pcie_pipelined(ctx, era, coeffs, deltas, case, True, names, hp, n4, narrow=True)
+        for p in hp:
+            ctx.lib.pgw_host_free(ctx.handle, p)
+    except Exception as e:      # noqa: BLE001
+        res['pcie_inclusive_reference'] = {'error': '%s: %s' % (type(e).__name__, e)}
     for v in list(era.values()) + list(deltas.dev.values()) + [deltas.ts_clim]:
         v.free()
     return res
@@ -763,7 +1137,8 @@ PMC_KERNEL = {'integ_geopot': 'k_integ_geopot', 'adjust_ps_step': 'k_adjust_ps_s
               'vert_interp_delta': 'k_vert_interp_delta', 'q_to_rh': 'k_humidity_hybrid', 'rh_to_q': 'k_humidity_hybrid',
               'finalize': 'k_finalize_ps_hus', 'pressure': 'k_pressure_levels',
               'thermo_delta': 'k_delta_pair<double, 2, true>', 'wind_delta': 'k_delta_pair<double, 2, false>',
-              'phi_ref_hybrid': 'k_phi_ref_hybrid', 'quad_delta': 'k_delta_quad', 'ps_loop_multi': 'k_ps_loop_multi'}
+              'phi_ref_hybrid': 'k_phi_ref_hybrid', 'quad_delta': 'k_delta_quad', 'ps_loop_multi': 'k_ps_loop_multi',
+              'interp_logp': 'k_interp_logp_stream', 'reinterp_pair': 'k_reinterp_pair'}
 
 
 def _profile_tag(a):
@@ -808,7 +1183,7 @@ def rocprof_frac(kernel, a, algo_GB):
     for f in files:
         r = row_of(f)
         tag = os.path.basename(f)[len('kernel_stats_'):].split('_')[0]
-        if r is not None and tag.startswith('r02'):
+        if r is not None and tag[:3] in ('r02', 'r03'):
             every[tag] = round(algo_GB / (float(r['timed_avg_us']) / 1e6) / HBM_PEAK_GBS, 4)
     r = row_of(files[-1])
     if r is None:

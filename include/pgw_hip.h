@@ -86,6 +86,10 @@ enum pgw_option {
 /* One context = one HIP device + one stream; replaces the implicit per-process state of a
  * reference worker (parallel.py:18-32: one process per file, no shared state). */
 int pgw_device_count(int *n);
+/* PCI address ("0000:c1:00.0", NUL-terminated; len >= 13) of HIP device `device`: the key under /sys/bus/pci/devices/ whose
+ * `numa_node` a rank binds its host threads and pinned buffers to (pgw4era5_amd/parallel.py bind_rank_to_numa).  The
+ * reference's workers are unplaced `multiprocessing.Pool` processes (parallel.py:18-32). */
+int pgw_device_pci_bus_id(int device, char *buf, int len);
 int pgw_ctx_create(int device, pgw_ctx **out);
 int pgw_ctx_destroy(pgw_ctx *ctx);
 int pgw_set_option(pgw_ctx *ctx, int option, int value);

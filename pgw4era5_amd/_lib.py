@@ -44,6 +44,7 @@ _vpp = C.POINTER(C.c_void_p)          # array of device pointers
 # name -> (restype, argtypes); must list every symbol declared in include/pgw_hip.h
 SIGNATURES = {
     'pgw_device_count': (_i, [_ip]),
+    'pgw_device_pci_bus_id': (_i, [_i, C.c_char_p, _i]),
     'pgw_ctx_create': (_i, [_i, C.POINTER(_vp)]),
     'pgw_ctx_destroy': (_i, [_vp]),
     'pgw_set_option': (_i, [_vp, _i, _i]),

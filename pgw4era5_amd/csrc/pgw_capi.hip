@@ -217,6 +217,15 @@ extern "C" int pgw_device_count(int *n) {
     return PGW_OK;
 }
 
+extern "C" int pgw_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 13) return PGW_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); buf[0] = 0; return PGW_ERR_ARG; }
+    hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
+    if (e != hipSuccess) { (void)hipGetLastError(); buf[0] = 0; return PGW_ERR_HIP; }   // not left behind for a later hipGetLastError()
+    return PGW_OK;
+}
+
 static int env_flag(const char *name, int dflt) {
     const char *e = getenv(name);
     if (!e || !e[0]) return dflt;

@@ -54,6 +54,129 @@ def band_max_hook(group=None):
     return hook
 
 
+# ---- rank placement on the host -----------------------------------------------------------------------------------
+# A rank moves 2.3 GB in and 2.3-4.6 GB out per file through pinned host buffers and runs reader / writer threads; on a
+# two-socket host with 8 GPUs both should sit on the socket (NUMA node) its GPU hangs off, and ranks should not share
+# cores.  The reference's Pool workers are unplaced (parallel.py:18-32).
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (the kernel's cpulist format) -> set of ints"""
+    out = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(ndev):
+    """NUMA node of HIP devices 0 .. ndev-1 (-1 where the kernel reports none): /sys/bus/pci/devices/<PCI address>/numa_node,
+    the address from the library (pgw_device_pci_bus_id)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    have = C.c_int(0)
+    lib.pgw_device_count(C.byref(have))
+    nodes = []
+    for d in range(ndev):
+        buf = C.create_string_buffer(32)
+        node = -1
+        # more ranks than devices (a rehearsal on a box with fewer GPUs): rank r uses device r mod count, like Context
+        if have.value > 0 and lib.pgw_device_pci_bus_id(d % have.value, buf, 32) == 0:
+            try:
+                with open('/sys/bus/pci/devices/%s/numa_node' % buf.value.decode().lower()) as f:
+                    node = int(f.read().strip())
+            except (OSError, ValueError):
+                node = -1
+        nodes.append(node)
+    return nodes
+
+
+def node_cpus(node):
+    try:
+        with open('/sys/devices/system/node/node%d/cpulist' % node) as f:
+            return parse_cpulist(f.read())
+    except OSError:
+        return set()
+
+
+def rank_cpu_set(local_rank, local_world, allowed, gpu_nodes=None, cpus_of_node=node_cpus):
+    """The CPUs rank `local_rank` of `local_world` ranks on this host binds to: the allowed CPUs (the process's affinity
+    mask: a container may own a slice of the host) of its GPU's NUMA node, divided evenly - disjoint, in rank order - among
+    the ranks whose GPUs share that node.  If any rank's node is unknown (-1) or has no allowed CPU, the allowed CPUs are
+    dealt evenly to all ranks instead (still disjoint).  Pure function of its arguments (tests/test_host_logic.py)."""
+    allowed = sorted(allowed)
+    gpu_nodes = list(gpu_nodes) if gpu_nodes is not None else [-1] * local_world
+    gpu_nodes += [-1] * (local_world - len(gpu_nodes))
+
+    def deal(pool, ranks, sets):
+        n = len(ranks)
+        if len(pool) < n:                       # fewer CPUs than ranks: they share them
+            for r in ranks:
+                sets[r] = list(pool)
+            return
+        base, extra = divmod(len(pool), n)
+        at = 0
+        for k, r in enumerate(ranks):
+            size = base + (1 if k < extra else 0)
+            sets[r] = pool[at:at + size]
+            at += size
+    by_node, sets = {}, {}
+    for r in range(local_world):
+        node = gpu_nodes[r]
+        pool = [c for c in allowed if c in cpus_of_node(node)] if node >= 0 else []
+        if not pool:
+            by_node = None
+            break
+        by_node.setdefault(node, (pool, []))[1].append(r)
+    if by_node is None:
+        deal(allowed, list(range(local_world)), sets)
+    else:
+        for pool, ranks in by_node.values():
+            deal(pool, ranks, sets)
+    return set(sets[local_rank])
+
+
+def bind_rank_to_numa(local_rank=None, local_world=None):
+    """Bind this process (and the threads it starts from now on: stage threads, NetCDF reader / writer pools) to its
+    rank's CPU set, before pinned host buffers are allocated so that they are placed on that node.  PGW_NUMA_BIND=0
+    switches it off.  Returns what was done, for logs and bench.py."""
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else int(local_rank)
+    if local_world is None:
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('PGW_LOCAL_WORLD', '1')))
+    info = {'local_rank': local_rank, 'local_world': local_world, 'bound': False}
+    if os.environ.get('PGW_NUMA_BIND', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        info['note'] = 'switched off' if hasattr(os, 'sched_setaffinity') else 'no sched_setaffinity on this platform'
+        return info
+    try:
+        allowed = os.sched_getaffinity(0)
+        try:
+            nodes = gpu_numa_nodes(local_world)
+        except Exception:                      # noqa: BLE001 - no library / no device: split the allowed CPUs evenly
+            nodes = [-1] * local_world
+        cpus = rank_cpu_set(local_rank, local_world, allowed, nodes)
+        os.sched_setaffinity(0, cpus)
+        info.update(bound=True, gpu_numa_node=nodes[local_rank] if local_rank < len(nodes) else -1, n_cpus=len(cpus),
+                    cpus=_cpulist(cpus), allowed_cpus=len(allowed))
+    except OSError as e:
+        info['note'] = 'sched_setaffinity failed: %s' % e
+    return info
+
+
+def _cpulist(cpus):
+    """set of ints -> '0-3,8' """
+    cpus = sorted(cpus)
+    parts, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else '%d-%d' % (cpus[i], cpus[j]))
+        i = j + 1
+    return ','.join(parts)
+
+
 def _merge(fargs, step_args):
     tasks = []
     for s in step_args:
@@ -125,7 +248,9 @@ def run_shard(func, tasks, indices, depth=None, io_threads=None):
 def _worker(rank, world, func, tasks, queue):
     os.environ['LOCAL_RANK'] = str(rank)
     os.environ['PGW_RANK'] = str(rank)
+    os.environ['PGW_LOCAL_WORLD'] = str(world)
     try:
+        bind_rank_to_numa(rank, world)                  # before the context, its pinned pools and the stage threads exist
         out = run_shard(func, tasks, shard_indices(len(tasks), rank, world))
         queue.put((rank, out, None))
     except BaseException as e:   # noqa: BLE001 - reported to the parent, which re-raises
@@ -202,6 +327,7 @@ class IterMP:
         err = None
         mine = []
         try:
+            bind_rank_to_numa()                          # LOCAL_RANK / LOCAL_WORLD_SIZE of torch.distributed.run
             mine = run_shard(func, tasks, shard_indices(len(tasks), rank, world))
         except Exception as e:            # noqa: BLE001 - every rank must reach the gather
             err = '%s: %s' % (type(e).__name__, e)

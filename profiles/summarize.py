@@ -62,6 +62,25 @@ def trace_stats():
             print(line, end='')
 
 
+def clean_rows(path):
+    """Rows of a rocprofv3 counter table with the dispatches of bench.py's side measurements dropped for the kernels of the
+    timed region: the PCIe-pipelined leg of `extras` runs copies (blit kernels) on two more streams, and the counters of a
+    file-path kernel that overlaps them include their instructions and bytes (r03a: 889 M instead of 593 M VALU
+    wave-instructions, 17.1 instead of 4.5 GB written per k_delta_quad launch).  `extras` starts with the step_02
+    regridding: a kernel that has dispatches before the first k_zonal_mean_rows / k_regrid dispatch is summarised from
+    those alone; kernels that only the side measurements launch keep all their dispatches."""
+    rows = list(csv.DictReader(open(path)))
+    cut = None
+    for r in rows:
+        if short(r['Kernel_Name']).startswith(('k_zonal_mean_rows', 'k_regrid')):
+            d = int(r['Dispatch_Id'])
+            cut = d if cut is None else min(cut, d)
+    if cut is None:
+        return rows
+    early = {short(r['Kernel_Name']) for r in rows if int(r['Dispatch_Id']) < cut}
+    return [r for r in rows if int(r['Dispatch_Id']) < cut or short(r['Kernel_Name']) not in early]
+
+
 def main():
     if sys.argv[1] == 'trace':
         return trace_stats()
@@ -81,7 +100,7 @@ def main():
         for kind, d in (('FETCH_SIZE', sys.argv[3]), ('WRITE_SIZE', sys.argv[4])):
             f = glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)[0]
             agg = collections.defaultdict(list)
-            for r in csv.DictReader(open(f)):
+            for r in clean_rows(f):
                 if r['Counter_Name'] == kind:
                     agg[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
             for k, v in agg.items():
@@ -94,7 +113,7 @@ def main():
         # wave-instructions per launch; SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles (x4 = cycles)
         f = glob.glob(os.path.join(sys.argv[5], '**', '*_counter_collection.csv'), recursive=True)[0]
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(f)):
+        for r in clean_rows(f):
             agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, v in agg.items():
             m = {c: sum(x) / len(x) for c, x in v.items()}

@@ -417,9 +417,51 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['collective']['ranks_counted_by_all_reduce'] == 2
     assert line['collective']['backend'] == 'gloo' and line['dry_run'] is True
+    # what an N-rank line reports beside the HBM-resident value: every rank's host placement (disjoint CPU sets here: two
+    # ranks, no GPU, the allowed CPUs dealt evenly), the per-rank PCIe-inclusive float32 leg, the all-ranks command line
+    pr = line['per_rank']
+    assert set(pr) >= {'affinity', 'affinity_disjoint', 'pcie_inclusive_f32_reference', 'end_to_end_cli_all_ranks'}
+    assert len(pr['affinity']) == 2 and [x['local_rank'] for x in pr['affinity']] == [0, 1]
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert all(x['bound'] for x in pr['affinity']) and pr['affinity_disjoint'] is True
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'],
                        capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE='1', RANK='0'))
     assert r.returncode == 2 and 'WORLD_SIZE is 1' in r.stderr
+
+
+def test_rank_cpu_sets_follow_the_gpus_numa_nodes_and_are_disjoint():
+    """parallel.rank_cpu_set: a rank's CPUs are the allowed CPUs of its GPU's NUMA node, dealt disjointly to the ranks
+    that share the node; unknown nodes or a container whose CPUs miss a node fall back to an even deal of the allowed
+    CPUs; the kernel's cpulist format round-trips."""
+    from pgw4era5_amd import parallel as P
+    nodes = {0: set(range(0, 64)) | set(range(128, 192)), 1: set(range(64, 128)) | set(range(192, 256))}
+    cpus_of = lambda n: nodes.get(n, set())
+    # an 8-GPU two-socket host: GPUs 0-3 on node 0, 4-7 on node 1
+    sets = [P.rank_cpu_set(r, 8, set(range(256)), [0, 0, 0, 0, 1, 1, 1, 1], cpus_of) for r in range(8)]
+    assert all(len(s) == 32 for s in sets)
+    assert all(not (sets[i] & sets[j]) for i in range(8) for j in range(i))
+    assert all(sets[r] <= nodes[0] for r in range(4)) and all(sets[r] <= nodes[1] for r in range(4, 8))
+    assert P._cpulist(sets[2]) == '128-159' and P.parse_cpulist('128-159') == sets[2]
+    assert P.parse_cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    # no NUMA information (this container): even, disjoint deal of the allowed CPUs
+    a, b = (P.rank_cpu_set(r, 2, set(range(16)), [-1, -1], cpus_of) for r in range(2))
+    assert a == set(range(8)) and b == set(range(8, 16))
+    # a container that owns CPUs of one node only while the GPUs sit on both: still disjoint
+    a, b = (P.rank_cpu_set(r, 2, set(range(100, 116)), [0, 1], cpus_of) for r in range(2))
+    assert not (a & b) and (a | b) == set(range(100, 116))
+    # more ranks than CPUs: shared, never empty
+    assert all(P.rank_cpu_set(r, 4, {0, 1, 2}, [0, 0, 0, 0], cpus_of) == {0, 1, 2} for r in range(4))
+    # bind: switched off by the environment, otherwise within the allowed set
+    before = os.sched_getaffinity(0)
+    try:
+        os.environ['PGW_NUMA_BIND'] = '0'
+        assert P.bind_rank_to_numa(0, 2)['bound'] is False and os.sched_getaffinity(0) == before
+        del os.environ['PGW_NUMA_BIND']
+        info = P.bind_rank_to_numa(1, 2)
+        assert info['bound'] and os.sched_getaffinity(0) <= before and P.parse_cpulist(info['cpus']) == os.sched_getaffinity(0)
+    finally:
+        os.environ.pop('PGW_NUMA_BIND', None)
+        os.sched_setaffinity(0, before)
 
 
 def test_bench_cpu_baseline_legs():
