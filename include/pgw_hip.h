@@ -79,7 +79,10 @@ enum pgw_option {
                                  count (consecutive ERA5 files of a run need the same number); initial value 6                  */
     PGW_OPT_FORCE_OFF64 = 5,  /* 1: the 64-bit byte-offset instantiations of the kernels that address arrays below 4 GiB with
                                  32-bit offsets (k_delta_quad, k_reinterp_pair) - test knob: the path a 0.125 deg L137 file takes    */
-    PGW_OPT_COUNT = 6
+    PGW_OPT_TEST_FAIL = 6,    /* test knob, default 0: pgw_step03_file fails on purpose - 1: the loop's workspace (ws_get), 2: before the
+                                 first loop launch, 3: before a continuation launch - so that the latitude-band protocol can be
+                                 tested where one band stops on its own                                                           */
+    PGW_OPT_COUNT = 7
 };
 
 /* ---------------------------------------------------------------- context ------------ */
@@ -104,6 +107,11 @@ int pgw_get_option(pgw_ctx *ctx, int option, int *value);
  * PGW_OPT_FULL_COLUMN = 0; fixed or local p_ref). */
 typedef int (*pgw_reduce_max_fn)(double *vals, int n, void *user);
 int pgw_set_reduce_hook(pgw_ctx *ctx, pgw_reduce_max_fn fn, void *user);
+/* A band that cannot even call pgw_step03_file for the file all bands are about to process (its host-side set-up raised:
+ * a failed upload, an out-of-memory) calls this instead: one reduce of the length the others' first loop launch makes,
+ * carrying `code`, so that their pgw_step03_file returns `code` instead of waiting for this band until the collective
+ * backend's timeout.  (A failure INSIDE pgw_step03_file does this by itself, whenever it happens.) */
+int pgw_band_abort(pgw_ctx *ctx, int code, int max_n_iter);
 const char *pgw_last_error(pgw_ctx *ctx);
 long long pgw_error_column(pgw_ctx *ctx);
 const char *pgw_version(void);

@@ -27,6 +27,10 @@ struct pgw_ctx {
     int last_passes_launched = 0;
     pgw_reduce_max_fn reduce_fn = nullptr;      // latitude-band sharding of one file: MAX over the ranks (pgw_set_reduce_hook)
     void *reduce_user = nullptr;
+    // protocol state of the band reduces of the file in progress (pgw_step03_file): how many have been made, how long the
+    // next one is (passes of the next loop launch), and whether the error being returned is one every band has seen
+    int band_reduces = 0, band_next_np = 0;
+    bool band_agreed = false;
     // options (pgw_set_option; defaults from the environment, read ONCE in pgw_ctx_create)
     int opt[PGW_OPT_COUNT];
     // vertical grid
@@ -250,6 +254,7 @@ extern "C" int pgw_ctx_create(int device, pgw_ctx **out) {
     c->opt[PGW_OPT_MULTIPASS] = env_flag("PGW_MULTIPASS", 1);
     c->opt[PGW_OPT_LOOP_GUESS] = 6;
     c->opt[PGW_OPT_FORCE_OFF64] = 0;
+    c->opt[PGW_OPT_TEST_FAIL] = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&c->d_status, (2 + MULTI_MAX_PASS) * sizeof(DevStatus)) != hipSuccess ||
         hipHostMalloc(&c->h_status, (2 + 2 * MULTI_MAX_PASS) * sizeof(DevStatus)) != hipSuccess ||
@@ -1044,7 +1049,9 @@ static int first_launch_passes(pgw_ctx *ctx, int max_n_iter) {
 }
 
 static int call_reduce(pgw_ctx *ctx, double *v, int n) {
+    ctx->band_reduces += 1;
     if (ctx->reduce_fn(v, n, ctx->reduce_user) != 0) {
+        ctx->band_agreed = true;                    // the exchange itself is broken: nobody is met by sending more
         ctx->err = "the reduce hook (pgw_set_reduce_hook) failed";
         ctx->err_col = -1;
         return PGW_ERR_REDUCE;
@@ -1052,20 +1059,33 @@ static int call_reduce(pgw_ctx *ctx, double *v, int n) {
     return PGW_OK;
 }
 
-// An error found before the loop's first launch: the other bands are about to wait in their first reduce - meet them
-// there with the status, so every rank returns it.
+// An error of THIS band only (a data error found before the loop's first launch, a failed allocation, a HIP error - at
+// any point of the file): the other bands are waiting, or about to wait, in their next reduce.  Meet them there with the
+// status - in the slot of the kernels before the loop while no reduce has been made, in the first pass's status slot of a
+// continuation launch afterwards - so every rank returns it instead of blocking until the backend's timeout.
 static int band_fail(pgw_ctx *ctx, int code, int max_n_iter) {
-    if (!ctx->reduce_fn || code == PGW_OK) return code;
+    if (!ctx->reduce_fn || code == PGW_OK || ctx->band_agreed) return code;
     const std::string text = ctx->err;
     const long long col = ctx->err_col;
-    const int np = first_launch_passes(ctx, max_n_iter);
+    const bool first = ctx->band_reduces == 0;
+    int np = first ? first_launch_passes(ctx, max_n_iter) : ctx->band_next_np;
+    if (np < 1) np = 1;
     double v[1 + 3 * MULTI_MAX_PASS];
-    v[0] = (double)code;
+    v[0] = first ? (double)code : 0.0;
     for (int k = 0; k < np; ++k) { v[1 + 3 * k] = 0.0; v[2 + 3 * k] = 0.0; v[3 + 3 * k] = -INFINITY; }
+    if (!first) v[1] = (double)code;
     call_reduce(ctx, v, 1 + 3 * np);
+    ctx->band_agreed = true;
     ctx->err = text;
     ctx->err_col = col;
     return code;
+}
+
+extern "C" int pgw_band_abort(pgw_ctx *ctx, int code, int max_n_iter) {
+    if (!ctx) return PGW_ERR_ARG;
+    ctx->band_reduces = 0; ctx->band_next_np = 0; ctx->band_agreed = false;
+    band_fail(ctx, code == PGW_OK ? PGW_ERR_ARG : code, max_n_iter);
+    return PGW_OK;
 }
 
 extern "C" int pgw_set_reduce_hook(pgw_ctx *ctx, pgw_reduce_max_fn fn, void *user) {
@@ -1091,6 +1111,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
     const long long n2 = (long long)ntime * ncol;
     void *state = nullptr;
     int rc;
+    if (ctx->opt[PGW_OPT_TEST_FAIL] == 1) return fail(ctx, PGW_ERR_HIP, "PGW_OPT_TEST_FAIL = 1: forced workspace failure (ws_get)");
     if ((rc = ws_get(ctx, 1, (size_t)n2 * 6 * sizeof(double), &state))) return rc;
     double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
     double *pref_f = adj_ps + n2;
@@ -1153,6 +1174,9 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             int np = first ? first_launch_passes(ctx, max_n_iter) : 2;    // (a caller-set guess <= 0 counts as 1)
             if (np > allowed) np = allowed;
             if (np < 1) np = 1;
+            ctx->band_next_np = np;
+            if (first && ctx->opt[PGW_OPT_TEST_FAIL] == 2) return fail(ctx, PGW_ERR_HIP, "PGW_OPT_TEST_FAIL = 2: forced failure before the first loop launch");
+            if (!first && ctx->opt[PGW_OPT_TEST_FAIL] == 3) return fail(ctx, PGW_ERR_HIP, "PGW_OPT_TEST_FAIL = 3: forced failure before a continuation launch");
             HIPCHK(ctx, hipMemcpyAsync(mst, hzero, sizeof(DevStatus) * np, hipMemcpyHostToDevice, ctx->stream));
             {
                 // one column per lane (two columns: 168 VGPRs + scratch; measured 1.36 vs 1.39 ms before the log table)
@@ -1191,6 +1215,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             }
             if (ctx->reduce_fn && (rc = call_reduce(ctx, red, 1 + 3 * np))) return rc;
             if (first && red[0] != 0.0) {                                  // earlier kernels of the file / the ERA-state scan
+                ctx->band_agreed = true;                                   // every band has this status now
                 const bool mine = hback[0].code != 0;                      // (else: another band's status)
                 if (mine) *ctx->h_status = hback[0];
                 const int code = mine ? (int)hback[0].code : (int)red[0];
@@ -1201,6 +1226,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             for (int k = 0; k < np && !conv; ++k) {
                 const DevStatus &h = hback[1 + k];
                 if (red[1 + 3 * k] != 0.0) {
+                    ctx->band_agreed = true;
                     const int code = h.code != 0 ? (int)h.code : (int)red[1 + 3 * k];
                     ctx->err_col = h.code != 0 ? (long long)h.col : -1;
                     ctx->err = status_text(code);
@@ -1211,6 +1237,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
                 if (max_err_hist && it - 1 < hist_len) max_err_hist[it - 1] = err_k;
                 it += 1;                                                   // :313
                 if (it > max_n_iter) {                                     // :315-319
+                    ctx->band_agreed = true;                               // decided from reduced figures: all bands stop here
                     if (n_iter) *n_iter = it - 1;
                     ctx->last_passes_launched = launched;
                     ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
@@ -1221,6 +1248,7 @@ static int run_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long ncol, const
             }
             first = false;
         }
+        ctx->band_agreed = true;       // every band leaves the loop here: nobody waits in a reduce of this file any more
         ctx->opt[PGW_OPT_LOOP_GUESS] = (it - 1) < 1 ? 1 : ((it - 1) > MULTI_MAX_PASS ? MULTI_MAX_PASS : (it - 1));
         ctx->last_levels_touched = touched;
         ctx->last_passes_launched = launched;
@@ -1310,7 +1338,18 @@ extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long 
 }
 
 // ------------------------------------------------------------------ whole file
+static int step03_file(pgw_ctx *ctx, pgw_file_args *a);
+
 extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
+    if (!ctx) return PGW_ERR_ARG;
+    ctx->band_reduces = 0; ctx->band_next_np = 0; ctx->band_agreed = false;
+    const int rc = step03_file(ctx, a);
+    // latitude-band mode: whatever made this band stop on its own - an argument check, a failed allocation, a data error
+    // before the loop, a HIP error between two loop launches - reaches the other bands through their next reduce
+    return (rc != PGW_OK && ctx->reduce_fn) ? band_fail(ctx, rc, a ? a->max_n_iter : 1) : rc;
+}
+
+static int step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     NEED(ctx, a != nullptr, "null args");
     const int dtype = a->dtype, ntime = a->ntime;
     const long long ncol = a->ncol;
@@ -1445,8 +1484,8 @@ extern "C" int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *a) {
             HIPCHK(ctx, hipGetLastError());
         }
         if (!defer) {
-            if ((rc = status_check(ctx))) return band_fail(ctx, rc, a->max_n_iter);
-            if ((rc = top_check())) return band_fail(ctx, rc, a->max_n_iter);
+            if ((rc = status_check(ctx))) return rc;            // (latitude-band mode: pgw_step03_file meets the other bands)
+            if ((rc = top_check())) return rc;
         }
     }
 

@@ -2162,7 +2162,13 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
     const long long n2 = (long long)ntime * ncol;
     long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
     long long ngroups = n2 / V;
-    if (g < ngroups) {
+    // The per-pass wave reductions below (wave_max, the __shfl_xor sum) need all 64 lanes: a lane beyond the last group
+    // (1440 x 721 columns leave 32 lanes of the last wave idle) walks the last group again - no stores, nothing contributed -
+    // instead of sitting out in a divergent branch, where the shuffles would read its registers undefined (a zero from
+    // there made an all-NaN partial wave "valid" with |err| = 0).
+    const bool live = g < ngroups;
+    if (!live) g = ngroups - 1;
+    {
         ColIdx ix = col_index(g, V, ncol);
         const int N = lv.nlev;
         long long c2 = ix.t * ncol + ix.c;
@@ -2182,8 +2188,10 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
                     if (REF && !zg.a) dphi[v] = (double)((float)zg.b[c2 + v] * (float)CON_G);      // see k_dphi_clim
                     else dphi[v] = zg.template get<REF>(c2 + v) * CON_G;                             // step_03:292-295
                 }
-                storev<double, V>(phi_ref_era + c2, phi_era);
-                storev<double, V>(dphi_clim + c2, dphi);
+                if (live) {
+                    storev<double, V>(phi_ref_era + c2, phi_era);
+                    storev<double, V>(dphi_clim + c2, dphi);
+                }
             }
 #pragma unroll
             for (int v = 0; v < V; ++v) { dps[v] = 0.0; adj[v] = 0.0; }                              // :182-184
@@ -2201,7 +2209,7 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
                 dps[v] = next_delta_ps<REF>(dps[v], adj[v]);              // step_03:192
                 ps[v] = ps_of<REF>(ps0[v], dps[v]);                       // :193
             }
-            storev<double, V>(dps_hist + (long long)k * n2 + c2, dps);
+            if (live) storev<double, V>(dps_hist + (long long)k * n2 + c2, dps);
             if (LOCAL) {
                 const double p_min_era = (loc.akN + ps0[0] * loc.bkN) * 0.95;                  // :227-228
                 const double p_min_pgw = (loc.akN + ps[0] * loc.bkN) * 0.95;                   // :229-230
@@ -2236,6 +2244,7 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
                 double ae = fabs(err);
                 if (ae == ae) amax = fmax(amax, ae);                                      // :308 skipna
             }
+            if (!live) { amax = -1.0; touched = 0; }
             double wm = wave_max(amax);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) touched += __shfl_xor(touched, off, 64);
@@ -2244,9 +2253,11 @@ __global__ __launch_bounds__(BLOCK, MULTI_MINW) void k_ps_loop_multi(Levels lv, 
                 atomicAdd(&s_touched[k], (unsigned long long)touched);
             }
         }
-        storev<double, V>(delta_ps + c2, dps);            // state after the last pass: a continuation launch resumes here
-        storev<double, V>(adj_ps + c2, adj);
-        if (LOCAL) {
+        if (live) {
+            storev<double, V>(delta_ps + c2, dps);        // state after the last pass: a continuation launch resumes here
+            storev<double, V>(adj_ps + c2, adj);
+        }
+        if (LOCAL && live) {
             loc.p_ref_col[c2] = pref[0]; loc.p_idx_col[c2] = idx;
             phi_ref_era[c2] = phi_era[0]; dphi_clim[c2] = dphi[0];
         }

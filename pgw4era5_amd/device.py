@@ -195,6 +195,16 @@ class Context:
         self._check(self.lib.pgw_set_reduce_hook(self.handle, cfn, None))
         self._reduce_cb = cfn
 
+    def has_reduce_hook(self):
+        return getattr(self, '_reduce_cb', None) is not None
+
+    def band_abort(self, code=None, max_n_iter=None):
+        """`pgw_band_abort`: this band cannot take part in the file the other bands are about to process (its set-up raised) -
+        meet them in their first reduce with an error status so that they fail too instead of waiting (needs the hook)."""
+        from . import settings as S
+        self.lib.pgw_band_abort(self.handle, int(_lib.PGW_ERR_REDUCE if code is None else code),
+                                int(S.max_n_iter if max_n_iter is None else max_n_iter))
+
     def side(self, name):
         """A second context on the same device (its own HIP stream), created on first use: 'h2d' / 'd2h' carry the file
         transfers of the pipelined driver so that uploads, kernels and downloads of consecutive files overlap (PCIe is
@@ -215,7 +225,7 @@ class Context:
         self._check(self.lib.pgw_sync(self.handle))
 
     def set_option(self, name, value):
-        """Per-context option of include/pgw_hip.h `enum pgw_option` ('quad', 'full_column', 'force_vec1', 'multipass', 'loop_guess', 'force_off64');
+        """Per-context option of include/pgw_hip.h `enum pgw_option` ('quad', 'full_column', 'force_vec1', 'multipass', 'loop_guess', 'force_off64', 'test_fail');
         returns the previous value."""
         old = self.get_option(name)
         self._check(self.lib.pgw_set_option(self.handle, _lib.OPTIONS[name], int(value)))
@@ -333,6 +343,14 @@ class PinnedPool:
 
     def owns(self, arr):
         return arr.ctypes.data in self._owned
+
+    def reclaim_all(self):
+        """Every buffer this pool ever handed out is free again - for use after an aborted pipeline run, when nothing
+        holds one any more (step_03_apply_to_era.reset_after_abort)."""
+        with self._lock:
+            self._free = {}
+            for size, arr in self._owned.values():
+                self._free.setdefault(size, []).append(arr)
 
     def close(self):
         with self._lock:

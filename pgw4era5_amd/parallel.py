@@ -220,6 +220,7 @@ def run_shard(func, tasks, indices, depth=None, io_threads=None):
         chains.append((i, pools[-1].submit(after(store, fut))))
 
     it = iter(indices)
+    failed = False
     try:
         for _ in range(depth):                           # bound the files in flight (host buffers, device sets)
             i = next(it, None)
@@ -233,6 +234,7 @@ def run_shard(func, tasks, indices, depth=None, io_threads=None):
             if i is not None:
                 submit(i)
     except BaseException:
+        failed = True
         if abort is not None:
             abort.set()
         for p in pools:
@@ -241,6 +243,10 @@ def run_shard(func, tasks, indices, depth=None, io_threads=None):
     finally:
         for p in pools:
             p.shutdown(wait=True)
+        # a chain cancelled between two stages never hands back what its finished stages took (a device buffer set, pinned
+        # buffers): once every stage thread has stopped, `func.reset` makes them all available again
+        if failed and callable(getattr(func, 'reset', None)):
+            func.reset()
     results.sort(key=lambda r: indices.index(r[0]))
     return results
 

@@ -371,9 +371,18 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     if dtype is None:
         dtype = np.asarray(era['T']).dtype
     dtype = np.dtype(dtype)
-    ds = DeltaSet(ctx, deltas, delta_times, plev, dtype)
-    e = _upload_era(ctx, era, dtype)
-    coeffs = dict(ak=era['ak'], bk=era['bk'], akm=era.get('akm'), bkm=era.get('bkm'), soil1=era['soil1'])
+    try:
+        ds = DeltaSet(ctx, deltas, delta_times, plev, dtype)
+        e = _upload_era(ctx, era, dtype)
+        coeffs = dict(ak=era['ak'], bk=era['bk'], akm=era.get('akm'), bkm=era.get('bkm'), soil1=era['soil1'])
+        if os.environ.get('PGW_TEST_FAIL_SETUP') == os.environ.get('RANK', '0') and ctx.has_reduce_hook():
+            raise MemoryError('PGW_TEST_FAIL_SETUP: forced failure of the host-side set-up of this band')
+    except BaseException:
+        # latitude-band mode: the other bands are on their way into pgw_step03_file and would wait for this one in their
+        # first reduce until the backend's timeout (gloo: 30 min) - tell them
+        if ctx.has_reduce_hook():
+            ctx.band_abort()
+        raise
     if i_reinterp:
         out, info = process_file_device_reinterp(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref)
     else:
@@ -433,9 +442,29 @@ def _io_raw():
 
 def _pinned_pool(ctx):
     from .device import PinnedPool
-    if id(ctx) not in _POOLS:
-        _POOLS[id(ctx)] = PinnedPool(ctx)
-    return _POOLS[id(ctx)]
+    with _BUFFER_LOCK:                              # the reader threads of the first two files arrive here together
+        if id(ctx) not in _POOLS:
+            _POOLS[id(ctx)] = PinnedPool(ctx)
+        return _POOLS[id(ctx)]
+
+
+def _release_pinned(pool, buf):
+    """Give a pinned buffer back to the pool it came from; a buffer the pool does not know is a bug of the pipeline (it
+    would never be recycled: 4.6 GB of pinned memory per float64 file), not something to pass over."""
+    if not pool.release(buf):
+        raise RuntimeError('a pinned buffer was released to a pool that does not own it')
+
+
+def reset_after_abort():
+    """parallel.run_shard calls this when a stage of the pipeline has failed and every stage thread has stopped: stage
+    chains that were cancelled between two stages may have held a device buffer set or pinned buffers - all of them are free
+    again, so that the next run in this process (a long-lived driver, a retry over the remaining files) finds them."""
+    with _BUFFER_LOCK:
+        for sets in _DEVICE_BUFFERS.values():
+            sets.reset()
+        for pool in _POOLS.values():
+            pool.reclaim_all()
+    _ABORT.clear()
 
 
 def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt,
@@ -463,7 +492,7 @@ def _stage_load(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_
         era_file = ncio.open_dataset(inp_era_file_path, decode_times=False, raw_big=raw, alloc=alloc)   # step_03:60
     except BaseException:
         for b_ in pinned:
-            pool.release(b_)
+            _release_pinned(pool, b_)
         raise
     vm = S.var_name_map
     dtype = np.dtype('float64') if era_file[vm['ta']].dtype.itemsize == 8 else np.dtype('float32')
@@ -498,9 +527,22 @@ class _BufferSets:
     def __init__(self, n):
         import queue
         self.inp, self.out = queue.Queue(), queue.Queue()
-        for _ in range(n):
-            self.inp.put({})
-            self.out.put({})
+        self.all_inp, self.all_out = [{} for _ in range(n)], [{} for _ in range(n)]
+        for a, b in zip(self.all_inp, self.all_out):
+            self.inp.put(a)
+            self.out.put(b)
+
+    def reset(self):
+        """all sets free again (after an aborted run: a cancelled stage chain may have held one)"""
+        import queue
+        for q, sets in ((self.inp, self.all_inp), (self.out, self.all_out)):
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            for x in sets:
+                q.put(x)
 
 
 _DEVICE_BUFFERS = {}
@@ -625,7 +667,7 @@ def _stage_download(item):
         dn.sync()
     except BaseException:
         for b_ in pinned_out:
-            pool.release(b_)
+            _release_pinned(pool, b_)
         raise
     finally:
         sets.out.put(out_set)
@@ -642,7 +684,7 @@ def _stage_download(item):
             keep = []
             for b_ in item['pinned']:
                 if b_.ctypes.data == base.ctypes.data:
-                    pool.release(b_)
+                    _release_pinned(pool, b_)
                 else:
                     keep.append(b_)
             item['pinned'] = keep
@@ -668,7 +710,7 @@ def _stage_store(item):
             pool = _pinned_pool(default_context())
             item['result'] = None
             for b_ in bufs:
-                pool.release(b_)
+                _release_pinned(pool, b_)
             item['pinned'], item['pinned_out'] = [], []
     if S.i_debug >= 1:
         print('Done. Saved to file {}.'.format(item['out_path']))
@@ -687,6 +729,7 @@ def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step
 
 pgw_for_era5.stages = (_stage_load, _stage_upload, _stage_compute, _stage_download, _stage_store)
 pgw_for_era5.abort = _ABORT
+pgw_for_era5.reset = reset_after_abort
 
 
 def _cli(argv=None):

@@ -422,6 +422,15 @@ if mode == 'poison_pref':
     case['era']['PS'][0, 17, 5] = 20000.0       # band 1 only: p_ref = 300 hPa lies below this "surface"
 if mode == 'poison_pshist':
     case['deltas']['ps_hist'][:, 17, 5] = 0.05  # band 1 only: historical surface pressure above the top delta level
+from pgw4era5_amd.device import default_context
+if mode == 'fail_ws' and rank == 1:
+    default_context().set_option('test_fail', 1)          # this band's loop workspace "cannot be allocated"
+if mode == 'fail_cont':
+    default_context().set_option('loop_guess', 2)         # a first launch of 2 passes, then continuation launches
+    if rank == 1:
+        default_context().set_option('test_fail', 3)      # ... and band 1 fails before its first continuation launch
+if mode == 'fail_setup':
+    os.environ['PGW_TEST_FAIL_SETUP'] = '1'               # band 1 raises in its host-side set-up, before the C call
 res = None
 try:
     for rep in range(2):                       # twice: the second file starts from the first one's pass count (loop_guess)
@@ -433,6 +442,8 @@ try:
     msg = 'ok'
 except ValueError as e:
     msg = 'ValueError: ' + str(e)
+except Exception as e:
+    msg = type(e).__name__ + ': ' + str(e)
 with open(os.path.join(out_dir, 'msg%%d.txt' %% rank), 'w') as f:
     f.write(msg)
 dist.barrier()
@@ -488,6 +499,25 @@ def test_a_band_that_fails_fails_all_bands(tmp_path, mode):
             assert msgs[r].startswith('ValueError: p_ref locally lies below the surface'), msgs
         else:
             assert msgs[r] == 'ValueError: ', msgs
+
+
+@pytest.mark.parametrize('mode', ['fail_ws', 'fail_cont', 'fail_setup'])
+def test_a_band_that_stops_on_its_own_does_not_leave_the_others_waiting(tmp_path, mode):
+    """Latitude-band mode: a band whose pgw_step03_file stops for a reason of its own - the loop's workspace cannot be had
+    (fail_ws, before any reduce), a failure between two loop launches (fail_cont, after the first reduce), its host-side
+    set-up raising before the C call (fail_setup) - meets the other band in that band's next reduce with an error status
+    (pgw_step03_file's wrapper / pgw_band_abort), so both ranks raise within seconds; without it the healthy band blocks in
+    dist.all_reduce until the backend's timeout (gloo: 30 minutes), which the 600 s limit of this test would catch."""
+    import time
+    t0 = time.time()
+    msgs = _run_bands(tmp_path, mode, port={'fail_ws': '29551', 'fail_cont': '29553', 'fail_setup': '29555'}[mode])
+    assert time.time() - t0 < 300
+    assert set(msgs) == {0, 1}
+    assert 'ok' not in msgs.values(), msgs
+    if mode == 'fail_setup':
+        assert msgs[1].startswith('MemoryError: PGW_TEST_FAIL_SETUP'), msgs
+    else:
+        assert 'PGW_OPT_TEST_FAIL' in msgs[1], msgs
 
 
 def test_randomised_file_layout_sweep():

@@ -1124,6 +1124,43 @@ def test_whole_file_odd_shapes(shape, dtype):
     np.testing.assert_allclose(got['QV'], want['QV'], rtol=tol if dtype == np.float64 else 3e-6, atol=1e-18)
 
 
+@pytest.mark.parametrize('which', ['all_nan', 'only_partial_wave_valid', 'only_partial_wave_nan'])
+def test_loop_maximum_with_a_partial_last_wave_and_nan_columns(which):
+    """step_03:308 takes the maximum of |phi error| with NaNs skipped (all NaN -> NaN, which ends the loop).  The loop
+    kernel reduces per wave; with 5 x 19 = 95 columns the last wave has 31 live lanes.  Columns are switched off by a NaN
+    surface geopotential (phi NaN, no error raised): everywhere (the history must read NaN, one pass - an idle lane
+    contributing a zero made it 0.0), everywhere but the partial wave, and in the partial wave only (the maximum of the first
+    pass is then finite, and the second pass raises like the reference)."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c = _case(5, 19, 24, seed=91, dtype=np.float64)
+    fis = c['era']['FIS'].reshape(-1)
+    if which == 'all_nan':
+        fis[:] = np.nan
+    elif which == 'only_partial_wave_valid':
+        fis[:64] = np.nan
+    else:
+        fis[64:] = np.nan
+    args = (c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    if which != 'all_nan':
+        # a NaN error makes the column's adjustment, hence its next surface pressure, NaN: pass 2 finds no half level below
+        # p_ref there and the reference raises (functions.py:162-165) - on both sides, whichever wave holds the column
+        for run in (s3.pgw_for_era5_arrays, O.pgw_for_era5_arrays):
+            with pytest.raises(ValueError, match='p_ref locally lies below the surface'):
+                run(*args)
+        return
+    got = s3.pgw_for_era5_arrays(*args)
+    want = O.pgw_for_era5_arrays(*args)
+    assert got['n_iter'] == want['n_iter']
+    np.testing.assert_allclose(np.asarray(got['max_err'])[:got['n_iter']], np.asarray(want['max_err'])[:got['n_iter']], rtol=1e-9,
+                               equal_nan=True)
+    if which == 'all_nan':                         # the same through the LOCAL form of the loop kernel (p_ref_inp = None)
+        loc = s3.pgw_for_era5_arrays(*args, p_ref='local')
+        assert loc['n_iter'] == 1 and np.isnan(loc['max_err'][0])
+    if which == 'all_nan':
+        assert got['n_iter'] == 1 and np.isnan(got['max_err'][0])
+    np.testing.assert_allclose(got['PS'], want['PS'], rtol=1e-9, equal_nan=True)
+
+
 def test_whole_file_plev34_and_exact_month():
     """34 delta levels (the Emon+Amon merge of step_01, Emon_add_top_from_Amon.sh:45,50) and a time stamp
     that hits a delta record exactly (no lerp, functions.py:282-283)."""

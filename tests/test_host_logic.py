@@ -663,6 +663,76 @@ def test_five_stage_pipeline_with_bounded_buffer_sets_and_abort():
         run_shard(func, tasks, list(range(12)))
     assert 'boom 5' in str(e.value) and abort.is_set()
     assert time.time() - t0 < 10
+    # A chain cancelled between two stages keeps what its finished stages took (file 6 or 7 may hold an input set whose
+    # compute stage never ran).  With `func.reset` (step_03_apply_to_era.reset_after_abort for the real driver) run_shard
+    # makes everything available again once all stage threads have stopped, and a second run in the same process works.
+    lost = 2 - sets_in.qsize()
+
+    def reset():
+        for q in (sets_in, sets_out):
+            while not q.empty():
+                q.get_nowait()
+            for i in range(2):
+                q.put(i)
+        in_use.update({'in': 0, 'out': 0})
+        abort.clear()
+    func.reset = reset
+    fail_at['x'] = 5
+    with pytest.raises(ValueError):
+        run_shard(func, tasks, list(range(12)))
+    assert sets_in.qsize() == 2 and sets_out.qsize() == 2 and not abort.is_set()
+    fail_at['x'] = None
+    assert run_shard(func, tasks, list(range(12))) == [(i, i * i) for i in range(12)]
+    assert lost >= 0
+
+
+def test_driver_buffer_sets_and_pinned_pool_are_whole_again_after_an_abort():
+    """step_03_apply_to_era.reset_after_abort: every device buffer set is back in its queue and every pinned buffer the
+    pool handed out is free again; releasing a buffer to a pool that does not own it is an error, not a silent leak."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import PinnedPool
+
+    class FakeCtx:                                     # PinnedPool only calls pgw_host_alloc / pgw_host_free through these
+        handle = None
+
+        class lib:
+            @staticmethod
+            def pgw_host_alloc(h, size, pp):
+                import ctypes as C
+                buf = (C.c_ubyte * size)()
+                FakeCtx.keep.append(buf)
+                C.cast(pp, C.POINTER(C.c_void_p))[0] = C.addressof(buf)
+                return 0
+
+            @staticmethod
+            def pgw_host_free(h, addr):
+                return 0
+        keep = []
+
+        @staticmethod
+        def _check(rc):
+            assert rc == 0
+    pool = PinnedPool(FakeCtx)
+    a, b = pool.acquire(100), pool.acquire(3 << 20)
+    assert pool.release(a) and pool.acquire(100).ctypes.data == a.ctypes.data        # recycled by size
+    other = PinnedPool(FakeCtx)
+    with pytest.raises(RuntimeError):
+        s3._release_pinned(other, b)
+    sets = s3._BufferSets(2)
+    x = sets.inp.get(); sets.out.get(); sets.out.get()
+    x['T'] = 'device array'
+    key = ('test-shape', '<f4')
+    s3._DEVICE_BUFFERS[key] = sets
+    s3._POOLS[-1] = pool
+    s3._ABORT.set()
+    try:
+        s3.reset_after_abort()
+        assert sets.inp.qsize() == 2 and sets.out.qsize() == 2 and not s3._ABORT.is_set()
+        assert any(s.get('T') == 'device array' for s in (sets.inp.get(), sets.inp.get()))   # the same sets, arrays kept
+        assert {pool.acquire(100).ctypes.data, pool.acquire(3 << 20).ctypes.data} == {a.ctypes.data, b.ctypes.data}
+    finally:
+        del s3._DEVICE_BUFFERS[key]
+        del s3._POOLS[-1]
 
 
 def test_run_starmap_keeps_the_reference_call_forms():
