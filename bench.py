@@ -292,9 +292,9 @@ def pcie_f32_leg(ctx, case, coeffs, np):
     finally:
         for p in hp:
             ctx.lib.pgw_host_free(ctx.handle, p)
-        for v in list(era.values()) + list(deltas.dev.values()) + [deltas.ts_clim]:
-            if v is not None:
-                v.free()
+        for v in era.values():
+            v.free()
+        deltas.free()
     return res
 
 
@@ -1062,8 +1062,9 @@ def f32_storage(ctx, case, coeffs, a, np, steps=10, warmup=2):
             ctx.lib.pgw_host_free(ctx.handle, p)
     except Exception as e:      # noqa: BLE001
         res['pcie_inclusive_reference'] = {'error': '%s: %s' % (type(e).__name__, e)}
-    for v in list(era.values()) + list(deltas.dev.values()) + [deltas.ts_clim]:
+    for v in era.values():
         v.free()
+    deltas.free()
     return res
 
 

@@ -358,6 +358,14 @@ typedef struct pgw_file_args {
     int passes_launched;  /* passes the loop kernels executed, including passes speculated beyond convergence (multi-pass launches) */
     unsigned long long levels_touched;
     double max_err_hist[32];
+    /* The reference loads every delta file on its own (load_delta, functions.py:195-303): files may have different time
+     * axes - monthly tos / siconc beside daily 3-D deltas - so a variable's bracketing records and abscissae are its own.
+     * per_var_time != 0: the records of zg, siconc, ts and tos are interpolated with the pairs below (x_hi == 0: the
+     * instant is a record of that file, `_a` ignored); x_hi / x_new above remain the pair of ta, hur, ua, va, tas, hurs and
+     * ps_hist, which the quad kernel interpolates together (a member of that group on another axis is handed over
+     * already interpolated by the caller, `_a` == `_b`).  per_var_time == 0: one pair for all (x_hi / x_new). */
+    int per_var_time, _pad1;
+    double zg_x_hi, zg_x_new, siconc_x_hi, siconc_x_new, ts_x_hi, ts_x_new, tos_x_hi, tos_x_new;
 } pgw_file_args;
 
 int pgw_step03_file(pgw_ctx *ctx, pgw_file_args *args);

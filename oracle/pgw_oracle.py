@@ -695,7 +695,7 @@ def pgw_for_era5_arrays_reinterp(era, deltas, delta_times, plev, target_dt,
     PS, T, QV, FIS = f64(era['PS']), f64(era['T']), f64(era['QV']), f64(era['FIS'])
     pa_hl_era, pa_era = hybrid_pressure(ak, bk, PS, akm, bkm)
     relhum = specific_to_relative_humidity(QV, pa_era, T)
-    ld = lambda name: load_delta_values(deltas[name], delta_times, target_dt)
+    ld = lambda name: load_delta_values(deltas[name], delta_times[name] if isinstance(delta_times, dict) else delta_times, target_dt)
     level1 = np.arange(1, len(ak) + 1)
     plev = np.asarray(plev, dtype=np.float64)
     kref = int(np.nonzero(plev == p_ref)[0][0])
@@ -752,7 +752,8 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt,
     relhum = specific_to_relative_humidity(QV, pa_era, T)             # :91-94
 
     def ld(name, target=target_dt):
-        return load_delta_values(deltas[name], delta_times, target)
+        # every delta file has its own time axis (load_delta per variable, functions.py:195-303): a dict gives them
+        return load_delta_values(deltas[name], delta_times[name] if isinstance(delta_times, dict) else delta_times, target)
 
     out = {}
     sic = sea_ice_update(np.asarray(era['FR_SEA_ICE'], dtype=np.float64), ld('siconc'))   # :103-107

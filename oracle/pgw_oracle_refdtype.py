@@ -308,7 +308,8 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     relhum = specific_to_relative_humidity(QV, pa_era, T)                 # :91-94
 
     def ld(name, target=target_dt):
-        return load_delta_values(deltas[name], delta_times, target)
+        # every delta file has its own time axis (load_delta per variable, functions.py:195-303): a dict gives them
+        return load_delta_values(deltas[name], delta_times[name] if isinstance(delta_times, dict) else delta_times, target)
 
     out = {}
     sic = np.array(era['FR_SEA_ICE'], copy=True)

@@ -1400,9 +1400,13 @@ static int step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         long long n = (long long)ntime * ncol;
         Prof pr(ctx, PGW_K_SURFACE);
         DISPATCH_TLV(dtype, ref, 1, {
-            DeltaSrc<T> dsic{(const T *)a->siconc_b, exact ? nullptr : (const T *)a->siconc_a, a->x_hi, a->x_new};
-            DeltaSrc<T> dts{(const T *)a->ts_b, exact ? nullptr : (const T *)a->ts_a, a->x_hi, a->x_new};
-            DeltaSrc<T> dtos{(const T *)a->tos_b, exact ? nullptr : (const T *)a->tos_a, a->x_hi, a->x_new};
+            // each delta file has its own time axis in the reference (load_delta per variable): own bracket, own abscissae
+            const double sx = a->per_var_time ? a->siconc_x_hi : a->x_hi, sn = a->per_var_time ? a->siconc_x_new : a->x_new;
+            const double tx = a->per_var_time ? a->ts_x_hi : a->x_hi, tn = a->per_var_time ? a->ts_x_new : a->x_new;
+            const double ox = a->per_var_time ? a->tos_x_hi : a->x_hi, on = a->per_var_time ? a->tos_x_new : a->x_new;
+            DeltaSrc<T> dsic{(const T *)a->siconc_b, sx == 0.0 ? nullptr : (const T *)a->siconc_a, sx, sn};
+            DeltaSrc<T> dts{(const T *)a->ts_b, tx == 0.0 ? nullptr : (const T *)a->ts_a, tx, tn};
+            DeltaSrc<T> dtos{(const T *)a->tos_b, ox == 0.0 ? nullptr : (const T *)a->tos_a, ox, on};
             hipLaunchKernelGGL((k_surface_update_lerp<T, REF>), dim3(nblocks(n, BLOCK)), dim3(BLOCK), 0, ctx->stream, ntime, ncol, st,
                                (const T *)a->FR_SEA_ICE, dsic, dtos, dts, (const T *)a->FR_LAND, (const T *)a->ts_clim,
                                (const T *)a->T_SKIN, (const T *)a->T_SO, (T *)a->FR_SEA_ICE_out, (T *)a->T_SKIN_out,
@@ -1494,8 +1498,8 @@ static int step03_file(pgw_ctx *ctx, pgw_file_args *a) {
     for (int i = 0; i < 32; ++i) a->max_err_hist[i] = NAN;
     if (a->local_p_ref) NEED(ctx, a->zg3_b != nullptr, "local_p_ref needs the full zg records (zg3_b / zg3_a)");
     rc = run_ps_loop(ctx, dtype, ntime, ncol, a->PS, a->FIS, a->T, a->QV, a->T_out, evap,
-                     a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a, a->x_hi,
-                     a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
+                     a->local_p_ref ? a->zg3_b : a->zg_b, a->local_p_ref ? a->zg3_a : a->zg_a,
+                     a->per_var_time ? a->zg_x_hi : a->x_hi, a->per_var_time ? a->zg_x_new : a->x_new, a->p_ref, a->adj_factor, a->thresh, a->max_n_iter, a->PS_out, a->QV_out, &a->n_iter,
                      a->max_err_hist, 32, a->local_p_ref ? a->nplev : 0, a->plev,
                      !check_top && !a->local_p_ref, qv_done, ref);
     a->levels_touched = ctx->last_levels_touched;

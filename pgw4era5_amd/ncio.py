@@ -400,6 +400,90 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, 
     return ds
 
 
+class RecordReader:
+    """One variable of a NetCDF-3 file read one record (index along its FIRST dimension) at a time: `pread` of that record's
+    bytes, byte order converted, decoded like `open_dataset` (`_FillValue` / `missing_value` -> NaN, scale / offset).  For
+    delta files whose records do not all fit on the device - 365 daily records of a 19-level 0.25 deg variable are 144 GB in
+    float32 - of which a run needs two at a time (load_delta, functions.py:240-292).  Everything else of the file (the
+    coordinates) is read once: `.coords` (times decoded), `.dims`, `.attrs`, `.nrec`, `.rec_shape`, `.dtype` (decoded)."""
+
+    def __init__(self, path, var, decode_times=True):
+        import os
+        self.path, self.var = path, var
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            try:
+                hdr = _parse_header(fd, os.fstat(fd).st_size)
+            except (ValueError, IndexError) as e:
+                raise IOError('%s is not a NetCDF-3 file (%s).' % (path, e))
+            byname = {v['name']: v for v in hdr['vars']}
+            if var not in byname:
+                raise KeyError(var)
+            v = byname[var]
+            if len(v['shape']) < 1:
+                raise ValueError('%s has no dimension to read records along' % var)
+            self._v, self._recsize = v, hdr['recsize']
+            self.dims, self.nrec, self.rec_shape = v['dims'], int(v['shape'][0]), tuple(int(n) for n in v['shape'][1:])
+            self._inner = int(np.prod(self.rec_shape, dtype=np.int64)) * v['dtype'].itemsize
+            self.coords = {}
+            for d in self.dims:
+                if d in byname and byname[d]['dims'] == (d,):
+                    c = byname[d]
+                    nrec = hdr['numrecs'] if c['record'] else 1
+                    buf = np.empty(c['nbytes'] * nrec, dtype=np.uint8)
+                    for r in range(nrec):
+                        if c['nbytes']:
+                            _pread_into(fd, buf[r * c['nbytes']:(r + 1) * c['nbytes']], c['begin'] + r * hdr['recsize'])
+                    arr = buf.view(c['dtype'].newbyteorder('>') if c['dtype'].itemsize > 1 else c['dtype']).reshape(c['shape'])
+                    arr = arr.astype(c['dtype'])
+                    arr, catt = mask_and_scale(arr, c['attrs'])
+                    if decode_times and 'since' in str(catt.get('units', '')):
+                        arr = decode_cf_time(arr, catt['units'], catt.get('calendar', 'standard'))
+                    self.coords[d] = arr
+            probe, self.attrs = mask_and_scale(np.zeros(1, dtype=v['dtype']), dict(v['attrs']))
+            self.dtype = probe.dtype
+        finally:
+            os.close(fd)
+        self._fd = None
+        self._lock = __import__('threading').Lock()
+
+    def read_record(self, r):
+        import os
+        r = int(r)
+        if not 0 <= r < self.nrec:
+            raise IndexError(r)
+        v = self._v
+        with self._lock:
+            if self._fd is None:
+                self._fd = os.open(self.path, os.O_RDONLY)
+        buf = np.empty(self._inner, dtype=np.uint8)
+        # a record variable's records are `recsize` apart; a fixed-size variable's first dimension is contiguous
+        off = v['begin'] + (r * self._recsize if v['record'] else r * self._inner)
+        if self._inner:
+            _pread_into(self._fd, buf, off)
+        arr = buf.view(v['dtype'].newbyteorder('>') if v['dtype'].itemsize > 1 else v['dtype']).reshape(self.rec_shape)
+        if v['dtype'].itemsize > 1:
+            arr = arr.byteswap(inplace=True).view(v['dtype'])
+        return mask_and_scale(arr, dict(v['attrs']))[0]
+
+    @property
+    def nbytes(self):
+        return self.nrec * int(np.prod(self.rec_shape, dtype=np.int64)) * self.dtype.itemsize
+
+    def close(self):
+        import os
+        with self._lock:
+            if self._fd is not None:
+                os.close(self._fd)
+                self._fd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:              # noqa: BLE001
+            pass
+
+
 def _open_dataset_scipy(path, decode_times=True, threads=4, decode_mask_scale=None):
     """The reader of the first version: scipy.io.netcdf_file over a memory map, every variable converted to a
     native-endian copy."""

@@ -77,50 +77,168 @@ def delta_time_bracket(delta_times, target):
 # deltas resident in HBM
 # ----------------------------------------------------------------------------------------
 class DeltaSet:
-    """All records of all climate deltas of one run, on the device.
+    """The climate deltas of one run on the device.
 
-    arrays: dict var -> host array [nrec, (nplev,) nlat, nlon] for ta,hur,ua,va,zg (4-D) and
-    tas,hurs,ts,tos,siconc,ps_hist (3-D).  `plev` in file order (descending for CMIP)."""
+    arrays: dict var -> [nrec, (nplev,) nlat, nlon] for ta,hur,ua,va,zg (4-D) and tas,hurs,ts,tos,siconc,ps_hist (3-D): a
+    host array, a DeviceArray, or a record provider (`ncio.RecordReader`: .nrec, .rec_shape, .read_record(r)).  `plev` in
+    file order (descending for CMIP).
+
+    Time axes: the reference loads every delta file on its own (load_delta, functions.py:195-303), so each variable has
+    its own time axis - `times_by_var[var]`, default `delta_times` - and is bracketed on it (monthly tos / siconc beside
+    daily 3-D deltas work).
+
+    HBM budget rule: all records of all variables stay resident when they fit into `PGW_DELTA_HBM_FRACTION` (default
+    0.35) of the device's memory - 12 monthly records of everything at 0.25 deg are 10 GB in float64.  Otherwise (365
+    daily records of five 19-level variables: 288 GB in float64, 144 GB in float32) a variable keeps a window of
+    `WINDOW` records on the device: consecutive ERA5 files need the same two, a new record is uploaded when the instant
+    moves past one (least recently used record dropped).  resident=True / False forces either."""
 
     VARS_3D = ('ta', 'hur', 'ua', 'va', 'zg')
     VARS_2D = ('tas', 'hurs', 'ts', 'tos', 'siconc', 'ps_hist')
+    WINDOW = 4
 
-    def __init__(self, ctx, arrays, delta_times, plev, dtype):
+    def __init__(self, ctx, arrays, delta_times, plev, dtype, times_by_var=None, resident=None):
         self.ctx = ctx
         self.dtype = np.dtype(dtype)
-        self.times = np.asarray(delta_times).astype('datetime64[s]')
+        self.times = None if delta_times is None else np.asarray(delta_times).astype('datetime64[s]')
         self.plev = np.ascontiguousarray(plev, dtype=np.float64)
-        self.dev = {}
-        for k in self.VARS_3D + self.VARS_2D:
-            if k in arrays:
-                a = arrays[k]
-                self.dev[k] = a if isinstance(a, DeviceArray) else ctx.to_device(np.ascontiguousarray(a, dtype=self.dtype), self.dtype)
+        self.plev_zg = self.plev                                    # zg_delta.nc may bring its own plev axis (load_delta_set)
+        self.times_by_var = {}
+        self.dev, self._src, self._cache, self._lock = {}, {}, {}, __import__('threading').Lock()
+        names = [k for k in self.VARS_3D + self.VARS_2D if k in arrays]
+        for k in names:
+            t = (times_by_var or {}).get(k)
+            t = self.times if t is None else np.asarray(t).astype('datetime64[s]')
+            if t is None:
+                raise ValueError('no time axis for %s' % k)
+            if self._nrec(arrays[k]) != len(t):
+                raise ValueError('time axis of %s has %d stamps, the array %d records' % (k, len(t), self._nrec(arrays[k])))
+            self.times_by_var[k] = t
+        if self.times is None and 'ta' in self.times_by_var:
+            self.times = self.times_by_var['ta']
+        total = sum(self._nrec(arrays[k]) * self._rec_elems(arrays[k]) for k in names) * self.dtype.itemsize
+        if resident is None:
+            forced = os.environ.get('PGW_DELTA_RESIDENT')
+            if forced in ('0', '1'):
+                resident = forced == '1'
+            else:
+                resident = total <= self.budget_bytes(ctx)
+        self.resident, self.total_bytes = bool(resident), int(total)
+        for k in names:
+            a = arrays[k]
+            if isinstance(a, DeviceArray):
+                self.dev[k] = a
+            elif self.resident:
+                if hasattr(a, 'read_record'):
+                    a = np.stack([a.read_record(r) for r in range(a.nrec)])
+                self.dev[k] = ctx.to_device(np.ascontiguousarray(a, dtype=self.dtype), self.dtype)
+            else:
+                self._src[k] = a
+                self._cache[k] = {}
         # annual-mean skin-temperature delta (step_03:134-136): depends on the delta file only
         if 'ts' in arrays:
+            _, _, _, _, keep = delta_time_bracket(self.times_by_var['ts'], self.times_by_var['ts'][0])
             ts = arrays['ts']
-            ts_h = ts.numpy() if isinstance(ts, DeviceArray) else np.asarray(ts)
-            _, _, _, _, keep = delta_time_bracket(self.times, self.times[0])
-            self.ts_clim = ctx.to_device(ts_h[keep].astype(np.float64).mean(axis=0).astype(self.dtype), self.dtype)
+            if isinstance(ts, DeviceArray):
+                mean = ts.numpy()[keep].astype(np.float64).mean(axis=0)
+            elif hasattr(ts, 'read_record'):
+                mean = np.zeros(ts.rec_shape, dtype=np.float64)
+                for r in keep:                                      # one record at a time: the file may not fit in host memory
+                    mean += ts.read_record(int(r)).astype(np.float64)
+                mean /= len(keep)
+            else:
+                mean = np.asarray(ts)[keep].astype(np.float64).mean(axis=0)
+            self.ts_clim = ctx.to_device(mean.astype(self.dtype), self.dtype)
         else:
             self.ts_clim = None
 
-    def bracket(self, target):
-        return delta_time_bracket(self.times, target)
+    @staticmethod
+    def _nrec(a):
+        return int(a.nrec) if hasattr(a, 'read_record') else int(a.shape[0])
+
+    @staticmethod
+    def _rec_elems(a):
+        shape = a.rec_shape if hasattr(a, 'read_record') else a.shape[1:]
+        return int(np.prod(shape, dtype=np.int64))
+
+    @staticmethod
+    def budget_bytes(ctx):
+        import ctypes
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        ctx._check(ctx.lib.pgw_mem_info(ctx.handle, ctypes.byref(free), ctypes.byref(total)))
+        return int(float(os.environ.get('PGW_DELTA_HBM_FRACTION', '0.35')) * total.value)
+
+    def __contains__(self, var):
+        return var in self.times_by_var
+
+    def rec(self, var, r):
+        """Record `r` of `var` on the device: a slab of the resident array, or the window's copy (uploaded now if absent)."""
+        r = int(r)
+        if var in self.dev:
+            return self.dev[var].slab(r)
+        with self._lock:
+            cache = self._cache[var]
+            if r in cache:
+                cache[r] = cache.pop(r)                             # most recently used last
+                return cache[r]
+            src = self._src[var]
+            host = src.read_record(r) if hasattr(src, 'read_record') else src[r]
+            if len(cache) >= self.WINDOW:
+                old = next(iter(cache))
+                arr = cache.pop(old)                                # reuse the buffer of the least recently used record
+                self.ctx.sync()                                     # no kernel may still read it
+                arr.copy_from(np.ascontiguousarray(host, dtype=self.dtype))
+            else:
+                arr = self.ctx.to_device(np.ascontiguousarray(host, dtype=self.dtype), self.dtype)
+            cache[r] = arr
+            return arr
+
+    def same_axis(self, var, ref='ta'):
+        a, b = self.times_by_var[var], self.times_by_var[ref]
+        return a is b or (len(a) == len(b) and bool(np.all(a == b)))
+
+    def bracket(self, target, var=None):
+        return delta_time_bracket(self.times if var is None else self.times_by_var[var], target)
+
+    def pair(self, var, target, scratch):
+        """(record before, record after, x_hi, x_new) of `var` for the instant, bracketed on its OWN time axis
+        (functions.py:240-283).  x_hi == 0: the instant is a record (the 'after' record is the same array)."""
+        ib, ia, x_hi, x_new, keep = self.bracket(target, var)
+        return self.rec(var, keep[ib]), self.rec(var, keep[ia]), x_hi, x_new
+
+    def pair_on_axis_of(self, var, target, main_x, scratch):
+        """The pair of `var` for kernels that interpolate a group of variables with ONE (x_hi, x_new) = main_x, the
+        bracket of `ta`: the records themselves when `var` shares ta's time axis, else `var` interpolated here on its own
+        axis and handed over as both records (b + (b - b) / x_hi * x_new = b).  `scratch(name, shape)` supplies the buffer.
+        (A float32 run holds that one field rounded to float32, where the fused path keeps the float64 value.)"""
+        if self.same_axis(var):
+            ib, ia, _, _, keep = self.bracket(target, 'ta')
+            return self.rec(var, keep[ib]), self.rec(var, keep[ia])
+        b, a, x_hi, x_new = self.pair(var, target, scratch)
+        if x_hi == 0.0:
+            return b, b
+        out = scratch('_pre_' + var, b.shape)
+        self.ctx._check(self.ctx.lib.pgw_time_lerp(self.ctx.handle, dtype_tag(self.dtype), b.size, b.ptr, a.ptr, x_hi, x_new,
+                                                   out.ptr))
+        return out, out
 
     def lerp2d(self, name, target, out=None):
-        """Time-interpolated 2-D delta (load_delta, functions.py:195-303) -> (1, nlat, nlon)."""
-        ib, ia, x_hi, x_new, keep = self.bracket(target)
-        a = self.dev[name]
-        b = a.slab(int(keep[ib]))
+        """Time-interpolated delta record (load_delta, functions.py:195-303) -> (1,) + record shape."""
+        b, a, x_hi, x_new = self.pair(name, target, None)
         if out is None:
             out = self.ctx.empty((1,) + b.shape, self.dtype)
         if x_hi == 0.0:
             self.ctx._check(self.ctx.lib.pgw_memcpy_d2d(self.ctx.handle, out.ptr, b.ptr, b.nbytes))
         else:
-            aa = a.slab(int(keep[ia]))
-            self.ctx._check(self.ctx.lib.pgw_time_lerp(self.ctx.handle, dtype_tag(self.dtype), b.size, b.ptr, aa.ptr,
+            self.ctx._check(self.ctx.lib.pgw_time_lerp(self.ctx.handle, dtype_tag(self.dtype), b.size, b.ptr, a.ptr,
                                                        x_hi, x_new, out.ptr))
         return out
+
+    def free(self):
+        for v in list(self.dev.values()) + [x for c in self._cache.values() for x in c.values()] + [self.ts_clim]:
+            if v is not None:
+                v.free()
+        self.dev, self._cache, self.ts_clim = {}, {}, None
 
 
 def _upload_era(ctx, era, dtype):
@@ -175,19 +293,22 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
             out[name] = ctx.empty(shape, dtype)
         return out[name]
 
-    ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)           # functions.py:224-283
-    rb, ra = int(keep[ib]), int(keep[ia])
+    _, _, x_hi, x_new, _ = deltas.bracket(target_dt, 'ta')          # functions.py:224-283, the axis of the quad group
     plev = deltas.plev
     a = _lib.FileArgs()
+    a.per_var_time = 1                                              # every delta file is bracketed on its own time axis
+    zb, za, a.zg_x_hi, a.zg_x_new = deltas.pair('zg', target_dt, buf)
     if local_p_ref:
+        if len(deltas.plev_zg) != len(plev) or np.any(deltas.plev_zg != plev):
+            raise NotImplementedError('p_ref_inp = None with a zg delta on other pressure levels than ta / hur / ua / va')
         a.local_p_ref = 1
-        a.zg3_b, a.zg3_a = deltas.dev['zg'].slab(rb).ptr, deltas.dev['zg'].slab(ra).ptr
+        a.zg3_b, a.zg3_a = zb.ptr, za.ptr
     else:
-        kref = np.nonzero(plev == p_ref)[0]                         # .sel(plev=p_ref), step_03:294
+        kref = np.nonzero(deltas.plev_zg == p_ref)[0]               # .sel(plev=p_ref), step_03:294
         if len(kref) != 1:
             raise KeyError(p_ref)
-        a.zg_b = deltas.dev['zg'].slab(rb).slab(int(kref[0])).ptr
-        a.zg_a = deltas.dev['zg'].slab(ra).slab(int(kref[0])).ptr
+        a.zg_b = zb.slab(int(kref[0])).ptr
+        a.zg_a = za.slab(int(kref[0])).ptr
         a.p_ref = float(p_ref)
     a.dtype, a.ntime, a.nlev, a.nplev, a.ncol = dtype_tag(dt), nt, N, len(plev), nlat * nlon
     a.ignore_top = 1 if ignore_top_pressure_error else 0
@@ -198,23 +319,27 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     for k in ('PS', 'FIS', 'T', 'QV', 'U', 'V'):
         setattr(a, k, era[k].ptr)
     a.plev = plev.ctypes.data_as(_dp)
-    dev = deltas.dev
-    for var in ('ta', 'hur', 'ua', 'va'):
-        setattr(a, var + '_b', dev[var].slab(rb).ptr)
-        setattr(a, var + '_a', dev[var].slab(ra).ptr)
-    for var, name in (('tas', 'tas'), ('hurs', 'hurs'), ('ps_hist', 'pshist')):
-        setattr(a, name + '_b', dev[var].slab(rb).ptr)
-        setattr(a, name + '_a', dev[var].slab(ra).ptr)
+    held = []                                                       # keeps the record arrays alive until the call returns
+    for var, name in (('ta', 'ta'), ('hur', 'hur'), ('ua', 'ua'), ('va', 'va'), ('tas', 'tas'), ('hurs', 'hurs'),
+                      ('ps_hist', 'pshist')):
+        b_, a_ = deltas.pair_on_axis_of(var, target_dt, (x_hi, x_new), buf)
+        held += [b_, a_]
+        setattr(a, name + '_b', b_.ptr)
+        setattr(a, name + '_a', a_.ptr)
     soil = None
-    if 'FR_SEA_ICE' in era and 'siconc' in dev:                     # surface riders, step_03:103-146
+    if 'FR_SEA_ICE' in era and 'siconc' in deltas:                  # surface riders, step_03:103-146
         soil = np.ascontiguousarray(coeffs['soil1'], dtype=np.float64)
         a.nsoil = len(soil)
         a.soil_depth = soil.ctypes.data_as(_dp)
         for k in ('T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE'):
             setattr(a, k, era[k].ptr)
         for var in ('siconc', 'ts', 'tos'):
-            setattr(a, var + '_b', dev[var].slab(rb).ptr)
-            setattr(a, var + '_a', dev[var].slab(ra).ptr)
+            b_, a_, vx_hi, vx_new = deltas.pair(var, target_dt, buf)
+            held += [b_, a_]
+            setattr(a, var + '_b', b_.ptr)
+            setattr(a, var + '_a', a_.ptr)
+            setattr(a, var + '_x_hi', vx_hi)
+            setattr(a, var + '_x_new', vx_new)
         a.ts_clim = deltas.ts_clim.ptr
         a.T_SKIN_out = buf('T_SKIN', era['T_SKIN'].shape).ptr
         a.T_SO_out = buf('T_SO', era['T_SO'].shape).ptr
@@ -257,11 +382,13 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
             out[name] = ctx.empty(shape, dtype)
         return out[name]
 
-    ib, ia, x_hi, x_new, keep = deltas.bracket(target_dt)
-    rb, ra = int(keep[ib]), int(keep[ia])
+    _, _, x_hi, x_new, _ = deltas.bracket(target_dt, 'ta')
     plev = deltas.plev
-    dev = deltas.dev
-    kref = np.nonzero(plev == p_ref)[0]
+    # records of the group the kernels interpolate with ta's (x_hi, x_new); a variable on another time axis comes
+    # interpolated on its own (DeltaSet.pair_on_axis_of)
+    R = {var: deltas.pair_on_axis_of(var, target_dt, (x_hi, x_new), buf)
+         for var in ('ta', 'hur', 'ua', 'va', 'tas', 'hurs', 'ps_hist')}
+    kref = np.nonzero(deltas.plev_zg == p_ref)[0]
     if len(kref) != 1:
         raise KeyError(p_ref)
     # ERA state: RELHUM (step_03:87-94), phi_ref_era, g*dzg (the 4-D pressure fields live in registers, k_reinterp_field)
@@ -270,11 +397,12 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     phi_era = buf('_phi_era', PS.shape, f64)
     ctx._check(lib.pgw_phi_ref_hybrid(h, tag, nt, ncol, T.ptr, QV.ptr, PS.ptr, FIS.ptr, float(p_ref), None, phi_era.ptr))
     dzg = buf('_dzg', PS.shape)
-    zb, za = dev['zg'].slab(rb).slab(int(kref[0])), dev['zg'].slab(ra).slab(int(kref[0]))
-    if x_hi == 0.0:
+    zb, za, zx_hi, zx_new = deltas.pair('zg', target_dt, buf)                   # zg_delta.nc on its own time axis
+    zb, za = zb.slab(int(kref[0])), za.slab(int(kref[0]))
+    if zx_hi == 0.0:
         ctx._check(lib.pgw_memcpy_d2d(h, dzg.ptr, zb.ptr, zb.nbytes))
     else:
-        ctx._check(lib.pgw_time_lerp(h, tag, zb.size, zb.ptr, za.ptr, x_hi, x_new, dzg.ptr))
+        ctx._check(lib.pgw_time_lerp(h, tag, zb.size, zb.ptr, za.ptr, zx_hi, zx_new, dzg.ptr))
     # loop state in buffers that live across files (a hipMalloc / hipFree per file synchronises the device)
     dphi = buf('_dphi', PS.shape, f64)
     dphi.copy_from(dzg.numpy().astype(np.float64) * CON_G)                        # step_03:292-293 (2-D, once)
@@ -289,13 +417,13 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
         def arr(*ptrs):
             return (C.c_void_p * 2)(*[p.ptr if hasattr(p, 'ptr') else p for p in ptrs])
         if var0 in ('ta', 'hur'):
-            sb = arr(dev[var0 + 's'].slab(rb), dev[var1 + 's'].slab(rb))
-            sa = arr(dev[var0 + 's'].slab(ra), dev[var1 + 's'].slab(ra))
-            pb, pa_ = dev['ps_hist'].slab(rb).ptr, dev['ps_hist'].slab(ra).ptr
+            sb = arr(R[var0 + 's'][0], R[var1 + 's'][0])
+            sa = arr(R[var0 + 's'][1], R[var1 + 's'][1])
+            pb, pa_ = R['ps_hist'][0].ptr, R['ps_hist'][1].ptr
         else:
             sb = sa = pb = pa_ = None
         ctx._check(lib.pgw_reinterp_pair(h, tag, nt, len(plev), ncol, plev.ctypes.data_as(_dp),
-                                         arr(dev[var0].slab(rb), dev[var1].slab(rb)), arr(dev[var0].slab(ra), dev[var1].slab(ra)),
+                                         arr(R[var0][0], R[var1][0]), arr(R[var0][1], R[var1][1]),
                                          x_hi, x_new, sb, sa, pb, pa_, arr(era0, era1), PS.ptr, ps_pgw.ptr,
                                          1 if ignore_top_pressure_error else 0, arr(target0, target1)))
 
@@ -306,9 +434,9 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     max_err = C.c_double()
     def arr(*xs):
         return (C.c_void_p * 2)(*[x.ptr for x in xs])
-    thermo = (arr(dev['ta'].slab(rb), dev['hur'].slab(rb)), arr(dev['ta'].slab(ra), dev['hur'].slab(ra)), x_hi, x_new,
-              arr(dev['tas'].slab(rb), dev['hurs'].slab(rb)), arr(dev['tas'].slab(ra), dev['hurs'].slab(ra)),
-              dev['ps_hist'].slab(rb).ptr, dev['ps_hist'].slab(ra).ptr)
+    thermo = (arr(R['ta'][0], R['hur'][0]), arr(R['ta'][1], R['hur'][1]), x_hi, x_new,
+              arr(R['tas'][0], R['hurs'][0]), arr(R['tas'][1], R['hurs'][1]),
+              R['ps_hist'][0].ptr, R['ps_hist'][1].ptr)
     while err > S.thresh_phi_ref_max_error:                                       # :189
         # one call and one host round trip per pass: delta_ps += adj_ps, ps_pgw (:192-193); ta / hur re-interpolated onto
         # the new levels (:202-216); the pass on them (:262-308)
@@ -324,7 +452,7 @@ def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top
     reinterp_pair('ua', 'va', era['U'], era['V'], buf('U', T.shape), buf('V', T.shape))   # :330-343
     ctx._check(lib.pgw_relative_to_specific_humidity_hybrid(h, tag, nt, ncol, hur_pgw.ptr, ps_pgw.ptr, ta_pgw.ptr,
                                                             buf('QV', T.shape).ptr))   # hus of the last pass, :262-266,370
-    if 'FR_SEA_ICE' in era and 'siconc' in dev:                                   # surface riders :103-146
+    if 'FR_SEA_ICE' in era and 'siconc' in deltas:                                # surface riders :103-146
         s3 = era['T_SKIN'].shape
         soil = np.ascontiguousarray(coeffs['soil1'], dtype=np.float64)
         ctx._check(lib.pgw_surface_update(
@@ -346,7 +474,7 @@ def _band_of(arrays, j0, j1):
 
 
 def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, dtype=None, i_reinterp=False, ref_dtype=None, band=None, reduce_max=None):
+                        p_ref=None, dtype=None, i_reinterp=False, ref_dtype=None, band=None, reduce_max=None, resident=None):
     """Whole-file path on in-memory host arrays (upload, compute on the GPU, download).
 
     band = (rank, world): this process handles latitude band `rank` of `world` of the file (parallel.band_rows) and
@@ -365,14 +493,17 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
         ctx.set_reduce_hook(reduce_max)
         try:
             return pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error, p_ref, dtype,
-                                       i_reinterp, ref_dtype)
+                                       i_reinterp, ref_dtype, resident=resident)
         finally:
             ctx.set_reduce_hook(None)
     if dtype is None:
         dtype = np.asarray(era['T']).dtype
     dtype = np.dtype(dtype)
     try:
-        ds = DeltaSet(ctx, deltas, delta_times, plev, dtype)
+        if isinstance(delta_times, dict):                 # one time axis per delta file, like the reference's load_delta
+            ds = DeltaSet(ctx, deltas, delta_times.get('ta'), plev, dtype, times_by_var=delta_times, resident=resident)
+        else:
+            ds = DeltaSet(ctx, deltas, delta_times, plev, dtype, resident=resident)
         e = _upload_era(ctx, era, dtype)
         coeffs = dict(ak=era['ak'], bk=era['bk'], akm=era.get('akm'), bkm=era.get('bkm'), soil1=era['soil1'])
         if os.environ.get('PGW_TEST_FAIL_SETUP') == os.environ.get('RANK', '0') and ctx.has_reduce_hook():
@@ -401,30 +532,42 @@ _DELTASETS = {}
 
 
 def load_delta_set(ctx, delta_input_dir, dtype):
-    """All delta files of a directory -> DeltaSet on the device, cached per process (every
-    ERA5 file of a run uses the same deltas)."""
+    """All delta files of a directory -> DeltaSet on the device, cached per process (every ERA5 file of a run uses the
+    same deltas).  Like the reference's load_delta (functions.py:195-303) every file brings its own time axis; the four
+    model-level variables must share one plev axis (the quad kernel interpolates them together), zg may have its own.
+    When all records fit the HBM budget (DeltaSet) the files are read whole; otherwise they are opened record-wise and
+    the DeltaSet keeps a window of records per variable on the device."""
     from . import ncio
     key = (os.path.abspath(delta_input_dir), np.dtype(dtype).str, ctx.device)
     if key in _DELTASETS:
         return _DELTASETS[key]
-    arrays, times, plev = {}, None, None
+    readers = {}
     for var in DeltaSet.VARS_3D + ('tas', 'hurs', 'ts', 'tos', 'siconc'):
-        ds = ncio.open_dataset(os.path.join(delta_input_dir, S.file_name_bases['SCEN-HIST'].format(var)))
-        arrays[var] = ds[var].values
-        t = np.asarray(ds[S.TIME_GCM].values)
-        if times is None:
-            times = t
-        elif len(t) != len(times) or np.any(t != times):
-            raise ValueError('time axis of %s differs from the other delta files' % var)
+        readers[var] = ncio.RecordReader(os.path.join(delta_input_dir, S.file_name_bases['SCEN-HIST'].format(var)), var)
+    readers['ps_hist'] = ncio.RecordReader(os.path.join(delta_input_dir, S.file_name_bases['HIST'].format('ps')), 'ps')
+    times, plevs = {}, {}
+    for var, r in readers.items():
+        if not r.dims or r.dims[0] != S.TIME_GCM or S.TIME_GCM not in r.coords:
+            raise ValueError('%s: the first dimension of %s must be %s with a coordinate variable' % (r.path, r.var, S.TIME_GCM))
+        times[var] = np.asarray(r.coords[S.TIME_GCM])
         if var in DeltaSet.VARS_3D:
-            p = np.asarray(ds[S.PLEV_GCM].values, dtype=np.float64)
-            if plev is None:
-                plev = p
-            elif len(p) != len(plev) or np.any(p != plev):
-                raise ValueError('plev axis of %s differs from the other delta files' % var)
-    ds = ncio.open_dataset(os.path.join(delta_input_dir, S.file_name_bases['HIST'].format('ps')))
-    arrays['ps_hist'] = ds['ps'].values
-    dset = DeltaSet(ctx, arrays, times, plev, dtype)
+            plevs[var] = np.asarray(r.coords[S.PLEV_GCM], dtype=np.float64)
+    plev = plevs['ta']
+    for var in ('hur', 'ua', 'va'):
+        if len(plevs[var]) != len(plev) or np.any(plevs[var] != plev):
+            raise ValueError('plev axis of %s differs from that of ta (the four model-level deltas are interpolated together)' % var)
+    total = sum(r.nrec * int(np.prod(r.rec_shape, dtype=np.int64)) for r in readers.values()) * np.dtype(dtype).itemsize
+    forced = os.environ.get('PGW_DELTA_RESIDENT')
+    resident = (forced == '1') if forced in ('0', '1') else total <= DeltaSet.budget_bytes(ctx)
+    if resident:
+        arrays = {}
+        for var, r in readers.items():
+            arrays[var] = ncio.open_dataset(r.path)[r.var].values               # whole file, threaded reads
+            r.close()
+    else:
+        arrays = readers
+    dset = DeltaSet(ctx, arrays, times['ta'], plev, dtype, times_by_var=times, resident=resident)
+    dset.plev_zg = plevs['zg']
     _DELTASETS[key] = dset
     return dset
 

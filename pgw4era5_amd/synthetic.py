@@ -297,10 +297,10 @@ def write_case_files(case, era_dir, delta_dir, era_name=None):
     name = era_name or S.era5_file_name_base.format(case['target_dt'])
     path = os.path.join(era_dir, name)
     ncio.to_netcdf(ds, path)
-    # deltas
-    times = case['delta_times']
-    tdays = (times - np.datetime64('1850-01-01T00:00:00')).astype('timedelta64[s]').astype(np.float64) / 86400.0
+    # deltas (case['delta_times']: one time axis for all files, or a dict var -> axis: every delta file has its own)
     for var, arr in case['deltas'].items():
+        times = case['delta_times'][var] if isinstance(case['delta_times'], dict) else case['delta_times']
+        tdays = (np.asarray(times).astype('datetime64[s]') - np.datetime64('1850-01-01T00:00:00')).astype('timedelta64[s]').astype(np.float64) / 86400.0
         dd = ncio.Dataset()
         dd['time'] = F(tdays, ('time',), attrs=dict(units='days since 1850-01-01 00:00:00', calendar='proleptic_gregorian'))
         dd['lat'] = F(cv['lat'], ('lat',))
@@ -315,3 +315,34 @@ def write_case_files(case, era_dir, delta_dir, era_name=None):
         dd[vname] = F(arr, dims)
         ncio.to_netcdf(dd, os.path.join(delta_dir, fname))
     return path
+
+
+def resample_deltas(case, stamps_by_var, seed=0, noise=0.02):
+    """Give the delta files of a make_case() result their own time axes (the reference loads every file on its own,
+    functions.py:195-303): `stamps_by_var[var]` = new stamps (datetime64) of that variable; its records are the monthly
+    records interpolated periodically to those stamps plus a little record-dependent noise (so that neighbouring records
+    differ and a wrong bracket shows).  Variables not named keep the 12 monthly records.  Returns (deltas, times_by_var)."""
+    rng = np.random.default_rng(seed)
+    base_t = np.asarray(case['delta_times']).astype('datetime64[s]')
+    doy = lambda t: (t - t.astype('datetime64[Y]')).astype('timedelta64[s]').astype(np.float64) / 86400.0
+    x0 = doy(base_t)
+    deltas, times = {}, {}
+    for var, arr in case['deltas'].items():
+        if var not in stamps_by_var:
+            deltas[var], times[var] = arr, base_t
+            continue
+        st = np.asarray(stamps_by_var[var]).astype('datetime64[s]')
+        x = doy(st)
+        xp = np.concatenate([[x0[-1] - 365.0], x0, [x0[0] + 365.0]])
+        a64 = np.asarray(arr, dtype=np.float64)
+        ext = np.concatenate([a64[-1:], a64, a64[:1]])
+        j = np.clip(np.searchsorted(xp, x, side='right') - 1, 0, len(xp) - 2)
+        w = ((x - xp[j]) / (xp[j + 1] - xp[j])).reshape((-1,) + (1,) * (a64.ndim - 1))
+        new = ext[j] * (1 - w) + ext[j + 1] * w
+        scale = np.nanstd(a64) or 1.0
+        new = new + noise * scale * rng.normal(size=(len(st),) + (1,) * (a64.ndim - 1))
+        new[np.isnan(ext[j]) | np.isnan(ext[j + 1])] = np.nan
+        if var == 'siconc':
+            new = np.minimum(new, 0.0)
+        deltas[var], times[var] = new.astype(arr.dtype), st
+    return deltas, times

@@ -96,6 +96,55 @@ def test_step03_fill_value_encoded_deltas(tmp_path):
     assert np.isnan(ds['U'].values).sum() == np.isnan(want['U']).sum() > 0
 
 
+def test_step03_daily_deltas_through_the_record_window(tmp_path, monkeypatch):
+    """Daily deltas - what step_02 `smoothing` produces - through the command line: 366 float32 records (a leap year's
+    calendar: Feb 29 is dropped, functions.py:224-230) for ta, hur, ua, va, zg, tas, hurs beside MONTHLY tos / siconc / ts /
+    ps_historical files (every delta file has its own time axis, functions.py:195-303), the record window forced
+    (PGW_DELTA_RESIDENT=0: at 0.25 deg these files are 144 GB and cannot stay resident).  ERA5 steps around the dropped
+    day and across the end of the year, each against the reference-dtype oracle with its own pass count; the resident
+    set writes the same bytes."""
+    from pgw4era5_amd import synthetic, step_03_apply_to_era as s3, ncio
+    base = synthetic.make_case(6, 8, 12, seed=17, dtype=np.float32)
+    day = np.timedelta64(1, 'D')
+    daily = np.datetime64('1996-01-01T12:00:00') + np.arange(366) * day
+    deltas, times = synthetic.resample_deltas(base, {k: daily for k in ('ta', 'hur', 'ua', 'va', 'zg', 'tas', 'hurs')}, seed=3)
+    steps = [dt.datetime(2007, 2, 28, 6), dt.datetime(2007, 2, 28, 18), dt.datetime(2007, 3, 1, 6),      # bracket (Feb 28, Mar 1)
+             dt.datetime(2007, 12, 31, 18), dt.datetime(2008, 1, 1, 6), dt.datetime(2008, 1, 1, 12)]      # year wrap; exact record
+    cases = []
+    for t in steps:
+        c = dict(base, deltas=deltas, delta_times=times, target_dt=t)
+        synthetic.write_case_files(c, str(tmp_path / 'era'), str(tmp_path / 'deltas'))
+        cases.append(c)
+    outs = {}
+    for resident in ('0', '1'):
+        monkeypatch.setenv('PGW_DELTA_RESIDENT', resident)
+        s3._DELTASETS.clear()
+        out_dir = str(tmp_path / ('out' + resident))
+        n_iters = []
+        for a, b in (('2007022806', '2007022818'), ('2007030106', '2007030106'), ('2007123118', '2007123118'),
+                     ('2008010106', '2008010112')):
+            n_iters += s3._cli(['-i', str(tmp_path / 'era'), '-o', out_dir, '-d', str(tmp_path / 'deltas'),
+                                '-f', a, '-l', b, '-H', '12' if a != '2008010106' else '6', '-p', '1', '-t'])
+        dset = list(s3._DELTASETS.values())[0]
+        assert dset.resident == (resident == '1')
+        if resident == '0':
+            assert not dset.dev and all(len(cache) <= s3.DeltaSet.WINDOW for cache in dset._cache.values())
+        outs[resident] = (out_dir, n_iters)
+    s3._DELTASETS.clear()
+    out_dir, n_iters = outs['0']
+    assert len(n_iters) == len(cases)
+    for c, n in zip(cases, n_iters):
+        want = R.pgw_for_era5_arrays(c['era'], deltas, times, c['plev'], c['target_dt'], True)
+        assert n == want['n_iter'], c['target_dt']
+        name = 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])
+        ds = ncio.open_dataset(os.path.join(out_dir, name), decode_times=False)
+        for k in ['PS', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+            np.testing.assert_allclose(ds[k].values, want[k], rtol=2.5e-7, atol=0, equal_nan=True, err_msg='%s %s' % (k, name))
+        for k in ['T', 'U', 'V']:
+            np.testing.assert_allclose(ds[k].values, want[k], rtol=1e-9, atol=1e-9, err_msg='%s %s' % (k, name))
+        assert open(os.path.join(out_dir, name), 'rb').read() == open(os.path.join(outs['1'][0], name), 'rb').read()
+
+
 def test_step03_non_convergence_names_the_file(files, monkeypatch):
     """step_03_apply_to_era.py:315-319: the error names the input file and the setting to raise."""
     from pgw4era5_amd import step_03_apply_to_era as s3, settings as S

@@ -691,6 +691,108 @@ def test_local_p_ref_mode_vs_oracle(dtype):
         np.testing.assert_allclose(ref['PS'], got['PS'], rtol=1.5e-6)
 
 
+def _mixed_axes_case(dtype, seed=31):
+    """A small file whose delta files have different time axes: ta, hur, va, tas, hurs, ps_hist monthly; ua on 24
+    half-month stamps (a member of the quad group on another axis); zg on 6 stamps; tos / siconc monthly but on other
+    days of the month; ts seasonal; the 3-D model-level variables also daily-ish in a second variant."""
+    from pgw4era5_amd import synthetic
+    c = synthetic.make_case(7, 9, 18, seed=seed, dtype=dtype)
+    day = np.timedelta64(1, 'D')
+    y0 = np.datetime64('1995-01-01T00:00:00')
+    stamps = dict(ua=y0 + np.arange(24) * 15 * day + 7 * day,
+                  zg=y0 + np.arange(6) * 61 * day + 30 * day,
+                  tos=y0 + np.arange(12) * 30 * day + 3 * day + np.timedelta64(6, 'h'),
+                  siconc=y0 + np.arange(12) * 30 * day + 3 * day + np.timedelta64(6, 'h'),
+                  ts=y0 + np.arange(4) * 91 * day + 45 * day)
+    deltas, times = synthetic.resample_deltas(c, stamps, seed=seed)
+    return c, deltas, times
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_per_variable_delta_time_axes_vs_oracle(dtype):
+    """The reference loads every delta file on its own (load_delta, functions.py:195-303): each variable is bracketed and
+    interpolated on ITS time axis.  Instants: inside the year, before every first record (wrap to the previous year), after
+    every last one, and exactly on a tos / siconc record (no interpolation for those two, functions.py:282-283).  float64
+    file against the float64 oracle, float32 file (reference-dtype mode) against the reference-dtype oracle; the record
+    window (resident=False) gives the bits of the resident set."""
+    import datetime as dt
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    c, deltas, times = _mixed_axes_case(dtype)
+    ora = O if dtype == np.float64 else R
+    on_tos_record = times['tos'][4].astype(dt.datetime).replace(year=2006)
+    for target in (dt.datetime(2006, 8, 2, 3), dt.datetime(2006, 1, 1, 0), dt.datetime(2006, 12, 31, 21), on_tos_record):
+        got = s3.pgw_for_era5_arrays(c['era'], deltas, times, c['plev'], target, True)
+        want = ora.pgw_for_era5_arrays(c['era'], deltas, times, c['plev'], target, True)
+        assert got['n_iter'] == want['n_iter'], target
+        if dtype == np.float64:
+            for k in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+                np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg='%s %s' % (k, target))
+        else:
+            for k in ['PS', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+                np.testing.assert_allclose(got[k], want[k], rtol=2.5e-7, atol=1e-7, equal_nan=True, err_msg='%s %s' % (k, target))
+            np.testing.assert_allclose(got['T'], want['T'], rtol=1e-9, err_msg=str(target))
+            np.testing.assert_allclose(got['V'], want['V'], rtol=1e-9, atol=1e-9, err_msg=str(target))
+            # ua sits on another axis than ta: it is interpolated in time before the quad kernel and held as ONE float32
+            # field there (the fused path keeps the float64 value): one float32 rounding of a delta of a few m/s
+            np.testing.assert_allclose(got['U'], want['U'], rtol=0, atol=4e-7 * np.abs(deltas['ua']).max() + 1e-9, err_msg=str(target))
+        win = s3.pgw_for_era5_arrays(c['era'], deltas, times, c['plev'], target, True, resident=False)
+        assert win['n_iter'] == got['n_iter']
+        for k in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+            np.testing.assert_array_equal(win[k], got[k], err_msg='window %s' % k)
+    # the same time axis handed over per variable is the one-axis call, bit for bit
+    one = s3.pgw_for_era5_arrays(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    per = s3.pgw_for_era5_arrays(c['era'], c['deltas'], {k: c['delta_times'] for k in c['deltas']}, c['plev'], c['target_dt'], True)
+    for k in ['PS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_SEA_ICE']:
+        np.testing.assert_array_equal(one[k], per[k], err_msg=k)
+
+
+def test_delta_record_window_keeps_few_records_on_the_device():
+    """DeltaSet with resident=False: at most WINDOW records of a variable live on the device, a record is uploaded once
+    while consecutive instants need it, and walking through the year (and across its end) returns the resident set's
+    records bit for bit."""
+    import datetime as dt
+    from pgw4era5_amd import step_03_apply_to_era as s3, synthetic
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    c = synthetic.make_case(4, 6, 10, seed=5)
+    day = np.timedelta64(1, 'D')
+    daily = np.datetime64('1996-01-01T12:00:00') + np.arange(366) * day            # a leap year: Feb 29 is dropped
+    deltas, times = synthetic.resample_deltas(c, {k: daily for k in ('ta', 'hur', 'ua', 'va', 'zg', 'tas', 'hurs')}, seed=2)
+    reads = []
+
+    class Provider:                                   # the interface of ncio.RecordReader over an in-memory array
+        def __init__(self, name, arr):
+            self.name, self.arr, self.nrec, self.rec_shape = name, arr, arr.shape[0], arr.shape[1:]
+
+        def read_record(self, r):
+            reads.append((self.name, r))
+            return self.arr[r]
+    win = s3.DeltaSet(ctx, {k: Provider(k, v) for k, v in deltas.items()}, None, c['plev'], np.float64, times_by_var=times, resident=False)
+    res = s3.DeltaSet(ctx, deltas, None, c['plev'], np.float64, times_by_var=times, resident=True)
+    assert not win.resident and res.resident and not win.dev
+    t = dt.datetime(2007, 2, 27, 0)
+    n_ts_reads = len([x for x in reads if x[0] == 'ts'])                            # ts was walked once for its annual mean
+    assert n_ts_reads == 12
+    del reads[:]
+    for step in range(40):                                                          # 3-hourly over Feb 28 -> Mar 3
+        for var in ('ta', 'tas', 'tos'):
+            b0, a0, x0, n0 = win.pair(var, t, None)
+            b1, a1, x1, n1 = res.pair(var, t, None)
+            assert (x0, n0) == (x1, n1)
+            np.testing.assert_array_equal(b0.numpy(), b1.numpy())
+            np.testing.assert_array_equal(a0.numpy(), a1.numpy())
+        assert all(len(cache) <= s3.DeltaSet.WINDOW for cache in win._cache.values())
+        t += dt.timedelta(hours=3)
+    ta_reads = [r for v, r in reads if v == 'ta']
+    assert len(ta_reads) == len(set(ta_reads)) <= 7                                 # five days: each record uploaded once
+    assert 59 not in ta_reads                                                       # record 59 = Feb 29, never needed
+    b, a, x_hi, x_new = win.pair('ta', dt.datetime(2007, 12, 31, 18), None)         # after the last record: wraps to the first
+    np.testing.assert_array_equal(a.numpy(), deltas['ta'][0])
+    np.testing.assert_array_equal(b.numpy(), deltas['ta'][365])
+    assert x_hi == 86400e9 and x_new == 6 * 3600e9
+    win.free(); res.free()
+
+
 def test_local_p_ref_no_candidate_error():
     from pgw4era5_amd import step_03_apply_to_era as s3
     c = _case(4, 5, 12, seed=22)

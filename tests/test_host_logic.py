@@ -96,6 +96,45 @@ def test_native_reader_matches_scipy_reader(tmp_path, monkeypatch):
         ncio.open_dataset(str(tmp_path / 'trunc.nc'))
 
 
+def test_record_reader_reads_one_record_at_a_time(tmp_path):
+    """ncio.RecordReader (delta files whose records do not all fit on the device): a variable's records one by one -
+    record variables (unlimited time, several of them: padded records) and fixed-size variables - equal to the whole-file
+    reader, `_FillValue` and packing decoded, the coordinates decoded once."""
+    from scipy.io import netcdf_file
+    from pgw4era5_amd import ncio
+    rng = np.random.default_rng(8)
+    for unlimited in (True, False):
+        p = str(tmp_path / ('r%d.nc' % unlimited))
+        nc = netcdf_file(p, 'w', version=2)
+        nc.createDimension('time', None if unlimited else 5); nc.createDimension('plev', 3)
+        nc.createDimension('lat', 4); nc.createDimension('lon', 7)
+        t = nc.createVariable('time', 'd', ('time',)); t.units = 'days since 1850-01-01 00:00:00'
+        pl = nc.createVariable('plev', 'd', ('plev',)); pl[:] = [1e5, 5e4, 1e4]
+        ta = nc.createVariable('ta', 'f', ('time', 'plev', 'lat', 'lon')); ta._FillValue = np.float32(1e20)
+        pk = nc.createVariable('tas', 'h', ('time', 'lat', 'lon')); pk.scale_factor = 0.01; pk.add_offset = 2.0
+        pk.missing_value = np.int16(-32767)
+        t[:] = 52960.5 + np.arange(5) * 30.0
+        a = rng.normal(size=(5, 3, 4, 7)).astype('f4'); a[2, 1, 0, 3] = 1e20
+        b = rng.integers(-3000, 3000, size=(5, 4, 7)).astype('i2'); b[4, 1, 1] = -32767
+        ta[:] = a; pk[:] = b
+        nc.close()
+        whole = ncio.open_dataset(p)
+        for name in ('ta', 'tas'):
+            r = ncio.RecordReader(p, name)
+            assert r.nrec == 5 and r.dims == whole[name].dims and r.rec_shape == whole[name].shape[1:]
+            assert r.dtype == whole[name].values.dtype
+            np.testing.assert_array_equal(r.coords['time'], whole['time'].values)
+            assert r.coords['time'].dtype.kind == 'M'
+            for i in (3, 0, 4, 2, 1):
+                np.testing.assert_array_equal(r.read_record(i), whole[name].values[i])
+            assert np.isnan(ncio.RecordReader(p, 'ta').read_record(2)[1, 0, 3])
+            with pytest.raises(IndexError):
+                r.read_record(5)
+            r.close()
+    with pytest.raises(KeyError):
+        ncio.RecordReader(p, 'nope')
+
+
 def test_native_reader_cdf5(tmp_path):
     """CDF-5 (64-bit data) header layout: counts, dimension ids and sizes are 64-bit, extra integer types.  No
     writer for this format exists in the build environment, so the file is assembled by hand from the format
