@@ -364,7 +364,12 @@ typedef struct pgw_file_args {
      * instant is a record of that file, `_a` ignored); x_hi / x_new above remain the pair of ta, hur, ua, va, tas, hurs and
      * ps_hist, which the quad kernel interpolates together (a member of that group on another axis is handed over
      * already interpolated by the caller, `_a` == `_b`).  per_var_time == 0: one pair for all (x_hi / x_new). */
-    int per_var_time, _pad1;
+    int per_var_time;
+    /* != 0: settings.i_reinterp = 1 (step_03_apply_to_era.py:202-216, 330-343) - in every pass of the loop the ERA ta / hur
+     * fields and their deltas are interpolated onto the CURRENT model-level pressures, ua / va once after convergence;
+     * fixed or local p_ref, every storage mode incl. ref_dtype.  One kernel sequence and one host read-back per pass
+     * (the multi-pass loop kernel needs iterate-independent T_pgw / e); no latitude-band sharding. */
+    int i_reinterp;
     double zg_x_hi, zg_x_new, siconc_x_hi, siconc_x_new, ts_x_hi, ts_x_new, tos_x_hi, tos_x_new;
 } pgw_file_args;
 

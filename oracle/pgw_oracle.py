@@ -686,7 +686,13 @@ def _zonal_mean(row):
 # ----------------------------------------------------------------------------------------
 def pgw_for_era5_arrays_reinterp(era, deltas, delta_times, plev, target_dt,
                                  ignore_top_pressure_error=False, p_ref=P_REF_INP):
-    """pgw_for_era5 with i_reinterp = 1 (step_03:202-216, 330-343) and fixed p_ref."""
+    """pgw_for_era5 with i_reinterp = 1 (step_03:202-216, 330-343) and fixed p_ref; p_ref=None (p_ref_inp = None, the local
+    reference level of :219-253): the general restatement of pgw_oracle_refdtype on float64 copies of the inputs."""
+    if p_ref is None:
+        from . import pgw_oracle_refdtype as R
+        f = lambda v: np.asarray(v, dtype=np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v
+        return R.pgw_for_era5_arrays_reinterp({k: f(v) for k, v in era.items()}, {k: f(v) for k, v in deltas.items()},
+                                              delta_times, plev, target_dt, ignore_top_pressure_error, p_ref=None)
     ak, bk = era['ak'], era['bk']
     akm, bkm = era.get('akm'), era.get('bkm')
     if akm is None:

@@ -344,3 +344,113 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
     out.update(PS=res['ps_pgw'], T=pgw['ta'], QV=res['hus_pgw'], U=pgw['ua'], V=pgw['va'],
                n_iter=res['n_iter'], max_err=res['max_err'], RELHUM_pgw=pgw['hur'])
     return out
+
+
+# ----------------------------------------------------------------------------------------
+# settings.i_reinterp = 1, fixed or local reference level      step_03:182-343, functions.py:434-477
+# ----------------------------------------------------------------------------------------
+def interp_logp_4d(var, source_P, targ_P, extrapolate='off'):
+    """functions.py:434-477 with numba's dtype flow (:575-578): `src_y[i2] - src_y[i1]` in var's dtype, the rest and the
+    result float64 (targ = xr.zeros_like(targ_P), targ_y = np.zeros)."""
+    var, source_P, targ_P = _a(var), _a(source_P), _a(targ_P)
+    if (var.shape[0] != source_P.shape[0]) or (var.shape[0] != targ_P.shape[0]):
+        raise ValueError('Time dimension of input files is inconsistent!')
+    nt, N, nlat, nlon = targ_P.shape
+    S = var.shape[1]
+    with np.errstate(invalid='ignore', divide='ignore'):
+        lsp, ltp = np.log(source_P), np.log(targ_P)
+    out = np.zeros(targ_P.shape, dtype=targ_P.dtype)
+    for t in range(nt):
+        sx = lsp[t].reshape(S, -1); sy = var[t].reshape(S, -1); tx = ltp[t].reshape(N, -1)
+        if np.any(sx[-1] < sx[0]):
+            raise ValueError('Source pressure values must be ascending!')
+        if np.any(tx[-1] < tx[0]):
+            raise ValueError('Target pressure values must be ascending!')
+        o, flag = O.interp_columns_vectorised(sx, sy, tx, extrapolate)
+        if extrapolate == 'off' and flag.any():
+            raise ValueError('Extrapolation deactivated but data out of bounds.')
+        out[t] = o.reshape(N, nlat, nlon)
+    return out
+
+
+def local_p_ref(pa_hl_era, pa_hl_pgw, plev, p_ref_last, idx_last):
+    """step_03:219-253 with determine_p_ref (functions.py:583-598) over all columns: the first plev (file order) below 95 %
+    of both surface pressures, never lower in altitude than in the previous pass.  Returns (p_ref, index into plev)."""
+    p_min_era = pa_hl_era[:, -1] * 0.95                              # :227-228
+    p_min_pgw = pa_hl_pgw[:, -1] * 0.95                              # :229-230
+    new = np.full(p_min_era.shape, np.nan)
+    idx = np.full(p_min_era.shape, -1, dtype=np.int64)
+    for k in range(len(plev) - 1, -1, -1):                           # first match in file order wins
+        ok = (p_min_era > plev[k]) & (p_min_pgw > plev[k])
+        new = np.where(ok, plev[k], new)
+        idx = np.where(ok, k, idx)
+    if p_ref_last is not None:                                       # min(p, p_ref_last), :598
+        lower = p_ref_last < new
+        new = np.where(lower, p_ref_last, new)
+        idx = np.where(lower, idx_last, idx)
+    if np.any(np.isnan(new)):                                        # :245-251
+        raise ValueError('No reference pressure level above the required local minimum pressure level '
+                         'could not be found everywhere.')
+    return new, idx
+
+
+def pgw_for_era5_arrays_reinterp(era, deltas, delta_times, plev, target_dt, ignore_top_pressure_error=False,
+                                 p_ref=O.P_REF_INP, adj_factor=O.ADJ_FACTOR, thresh=O.THRESH_PHI_REF_MAX_ERROR,
+                                 max_n_iter=O.MAX_N_ITER):
+    """pgw_for_era5 with i_reinterp = 1 (step_03:202-216, 330-343), p_ref fixed or None (p_ref_inp = None: :219-253), in
+    the reference's dtype flow: on float32 files interp_logp_4d of the float32 ERA temperature gives float64 with float32
+    value differences, RELHUM and every delta are float64, delta_ps / ps_pgw float32, phi_hl float32.  On float64 inputs
+    this is pgw_oracle.pgw_for_era5_arrays_reinterp (tests/test_oracle_refdtype.py)."""
+    ak, bk = _a(era['ak']), _a(era['bk'])
+    akm, bkm = era.get('akm'), era.get('bkm')
+    if akm is None:
+        akm, bkm = full_level_coeffs(ak, bk)
+    PS, T, QV, FIS = _a(era['PS']), _a(era['T']), _a(era['QV']), _a(era['FIS'])
+    pa_hl_era, pa_era = hybrid_pressure(ak, bk, PS, akm, bkm)
+    relhum = specific_to_relative_humidity(QV, pa_era, T)                 # :91-94
+    ld = lambda name: load_delta_values(deltas[name], delta_times[name] if isinstance(delta_times, dict) else delta_times, target_dt)
+    level1 = np.arange(1, len(ak) + 1)
+    plev = np.asarray(plev, dtype=np.float64)
+    zg = ld('zg')
+    era_fields = dict(ta=T, hur=relhum, ua=_a(era['U']), va=_a(era['V']))
+
+    def reinterp(var, pa_pgw):
+        e = interp_logp_4d(era_fields[var], pa_era, pa_pgw, extrapolate='constant')          # :209-211
+        dsfc, psh = (ld(var + 's'), ld('ps_hist')) if var in ('ta', 'hur') else (None, None)
+        return e + vert_interp_delta(ld(var), plev, pa_pgw, dsfc, psh, ignore_top_pressure_error)   # :212-216
+
+    delta_ps = np.zeros_like(PS)                                          # :182
+    adj_ps = np.zeros_like(PS)                                            # :184
+    err_max = np.inf
+    it = 1
+    hist = []
+    pref, idx = None, None
+    while err_max > thresh:
+        np.add(delta_ps, adj_ps, out=delta_ps, casting='same_kind')       # :192
+        ps_pgw = PS + delta_ps                                            # :193
+        pa_hl_pgw, pa_pgw = hybrid_pressure(ak, bk, ps_pgw, akm, bkm)
+        ta_pgw, hur_pgw = reinterp('ta', pa_pgw), reinterp('hur', pa_pgw)
+        if p_ref is None:
+            pref, idx = local_p_ref(pa_hl_era, pa_hl_pgw, plev, pref, idx)
+            dzg = np.take_along_axis(zg, idx[:, None], axis=1)[:, 0]      # .sel(plev=p_ref), :294
+            pr = pref
+        else:
+            kref = np.nonzero(plev == p_ref)[0]
+            if len(kref) != 1:
+                raise KeyError(p_ref)
+            dzg = zg[:, kref[0]]
+            pr = p_ref
+        hus_pgw = relative_to_specific_humidity(hur_pgw, pa_pgw, ta_pgw)                     # :262-266
+        phi_ref_pgw = integ_geopot(pa_hl_pgw, FIS, ta_pgw, hus_pgw, level1, pr)              # :269-276
+        phi_ref_era = integ_geopot(pa_hl_era, FIS, T, QV, level1, pr)                        # :280-287
+        err = (phi_ref_pgw - phi_ref_era) - dzg * CON_G                                      # :289-298
+        adj_ps = - adj_factor * ps_pgw / (CON_RD * ta_pgw[:, -1]) * err                       # :301-304
+        a = np.abs(err)
+        err_max = np.nanmax(a) if not np.all(np.isnan(a)) else np.nan                        # :308
+        hist.append(float(err_max))
+        it += 1
+        if it > max_n_iter:                                                                   # :313-319
+            raise ValueError('ERROR! Pressure adjustment did not converge')
+    return dict(PS=ps_pgw, T=ta_pgw, QV=hus_pgw, U=reinterp('ua', pa_pgw), V=reinterp('va', pa_pgw),
+                RELHUM_pgw=hur_pgw, n_iter=it - 1, max_err=hist, p_ref=pref)
+

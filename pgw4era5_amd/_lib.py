@@ -117,7 +117,7 @@ class FileArgs(C.Structure):
         [(n, C.c_void_p) for n in ('PS_out', 'T_out', 'QV_out', 'U_out', 'V_out', 'hur_pgw_out',
                                    'T_SKIN_out', 'T_SO_out', 'FR_SEA_ICE_out')] +
         [('n_iter', C.c_int), ('passes_launched', C.c_int), ('levels_touched', C.c_ulonglong),
-         ('max_err_hist', C.c_double * 32), ('per_var_time', C.c_int), ('_pad1', C.c_int)] +
+         ('max_err_hist', C.c_double * 32), ('per_var_time', C.c_int), ('i_reinterp', C.c_int)] +
         [(n, C.c_double) for n in ('zg_x_hi', 'zg_x_new', 'siconc_x_hi', 'siconc_x_new', 'ts_x_hi', 'ts_x_new',
                                    'tos_x_hi', 'tos_x_new')])
 

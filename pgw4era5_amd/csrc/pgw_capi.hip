@@ -778,28 +778,34 @@ extern "C" int pgw_reinterp_field(pgw_ctx *ctx, int dtype, int ntime, int nplev,
     return PGW_OK;
 }
 
-template <typename T, bool SFC, typename O, bool EVAP>
-static void launch_reinterp_pair_o(pgw_ctx *ctx, const Levels &lv, int ntime, long long ncol, const ReinterpPair<T> &rv,
+template <typename T, bool SFC, typename O, bool EVAP, typename TE0, typename TE1, typename TO, bool REF>
+static void launch_reinterp_pair_o(pgw_ctx *ctx, const Levels &lv, int ntime, long long ncol, const ReinterpPair<T, TE0, TE1, TO> &rv,
                                    const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, int check_top) {
-    hipLaunchKernelGGL((k_reinterp_pair<T, SFC, O, EVAP>), dim3(nblocks((long long)ntime * ncol, BLOCK)), dim3(BLOCK),
+    hipLaunchKernelGGL((k_reinterp_pair<T, SFC, O, EVAP, TE0, TE1, TO, REF>), dim3(nblocks((long long)ntime * ncol, BLOCK)), dim3(BLOCK),
                        2 * lv.nlev * sizeof(double), ctx->stream, ctx->plev_tab, lv, ntime, ncol, rv, p, ps_era, ps_pgw,
                        check_top, ctx->d_status);
 }
-template <typename T>
-static void launch_reinterp_pair(pgw_ctx *ctx, const Levels &lv, int ntime, int nplev, long long ncol, const ReinterpPair<T> &rv,
+template <typename T, typename TE0 = T, typename TE1 = T, typename TO = T, bool REF = false>
+static void launch_reinterp_pair(pgw_ctx *ctx, const Levels &lv, int ntime, int nplev, long long ncol,
+                                 const ReinterpPair<T, TE0, TE1, TO> &rv,
                                  const DeltaSrc<T> &p, const T *ps_era, const T *ps_pgw, bool sfc, int check_top) {
     // 32-bit byte offsets when every array (fields: nlev levels, delta records: nplev levels) is smaller than 4 GiB
-    const unsigned long long big = (unsigned long long)ntime * (lv.nlev > nplev ? lv.nlev : nplev) * ncol * sizeof(T);
+    const unsigned long long big = (unsigned long long)ntime * (lv.nlev > nplev ? lv.nlev : nplev) * ncol * sizeof(TO);
     const bool o32 = big < (1ull << 32) && !ctx->opt[PGW_OPT_FORCE_OFF64];
     if (rv.evap) {                                       // the loop's ta + hur pair (always with the surface insertion)
-        if (o32) launch_reinterp_pair_o<T, true, boff32, true>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-        else launch_reinterp_pair_o<T, true, boff64, true>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-    } else if (o32) {
-        if (sfc) launch_reinterp_pair_o<T, true, boff32, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-        else launch_reinterp_pair_o<T, false, boff32, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-    } else {
-        if (sfc) launch_reinterp_pair_o<T, true, boff64, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
-        else launch_reinterp_pair_o<T, false, boff64, false>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        if (o32) launch_reinterp_pair_o<T, true, boff32, true, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, true, boff64, true, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+    } else if constexpr (!REF) {
+        if (o32) {
+            if (sfc) launch_reinterp_pair_o<T, true, boff32, false, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+            else launch_reinterp_pair_o<T, false, boff32, false, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        } else {
+            if (sfc) launch_reinterp_pair_o<T, true, boff64, false, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+            else launch_reinterp_pair_o<T, false, boff64, false, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        }
+    } else {                                             // reference-dtype mode without EVAP: the ua + va pair after the loop
+        if (o32) launch_reinterp_pair_o<T, false, boff32, false, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
+        else launch_reinterp_pair_o<T, false, boff64, false, TE0, TE1, TO, REF>(ctx, lv, ntime, ncol, rv, p, ps_era, ps_pgw, check_top);
     }
 }
 
@@ -829,9 +835,9 @@ extern "C" int pgw_reinterp_pair(pgw_ctx *ctx, int dtype, int ntime, int nplev, 
             for (int v = 0; v < 2; ++v) {
                 rv.d[v] = DeltaSrc<T>{(const T *)delta_b[v], lerp ? (const T *)delta_a[v] : nullptr, x_hi, x_new};
                 rv.sfc[v] = DeltaSrc<T>{dsfc_b ? (const T *)dsfc_b[v] : nullptr, (dsfc_b && lerp) ? (const T *)dsfc_a[v] : nullptr, x_hi, x_new};
-                rv.era[v] = (const T *)era_field[v];
                 rv.out[v] = (T *)out[v];
             }
+            rv.era0 = (const T *)era_field[0]; rv.era1 = (const T *)era_field[1];
             rv.evap = nullptr;
             DeltaSrc<T> p{(const T *)pshist_b, lerp ? (const T *)pshist_a : nullptr, x_hi, x_new};
             launch_reinterp_pair<T>(ctx, lv, ntime, nplev, ncol, rv, p, (const T *)ps_era, (const T *)ps_pgw, dsfc_b != nullptr,
@@ -989,7 +995,7 @@ extern "C" int pgw_reinterp_pass(pgw_ctx *ctx, int dtype, int ntime, int nplev, 
                 rv.d[v] = DeltaSrc<T>{(const T *)delta_b[v], lerp ? (const T *)delta_a[v] : nullptr, x_hi, x_new};
                 rv.sfc[v] = DeltaSrc<T>{(const T *)dsfc_b[v], lerp ? (const T *)dsfc_a[v] : nullptr, x_hi, x_new};
             }
-            rv.era[0] = (const T *)T_era; rv.era[1] = (const T *)RELHUM_era;
+            rv.era0 = (const T *)T_era; rv.era1 = (const T *)RELHUM_era;
             rv.out[0] = (T *)ta_pgw; rv.out[1] = (T *)hur_pgw;
             rv.evap = (T *)evap;
             DeltaSrc<T> p{(const T *)pshist_b, lerp ? (const T *)pshist_a : nullptr, x_hi, x_new};
@@ -1337,6 +1343,177 @@ extern "C" int pgw_adjust_ps_loop(pgw_ctx *ctx, int dtype, int ntime, long long 
                        adj_factor, thresh, max_n_iter, ps_pgw, hus_pgw, n_iter, max_err_hist, max_n_iter);
 }
 
+// ------------------------------------------------------------------ whole file, settings.i_reinterp = 1
+// step_03_apply_to_era.py:182-343 with i_reinterp = 1: in every pass the ERA ta / hur fields and their deltas are
+// interpolated onto the CURRENT model-level pressures (:202-216), ua / va once after convergence (:330-343).  Fixed or local
+// reference level (p_ref_inp = None, :219-253), float64 / float32 storage, reference-dtype mode on float32 files.  One launch
+// sequence and one host read-back (max |err|, status) per pass - the loop control is the reference's.
+static int run_reinterp_file(pgw_ctx *ctx, pgw_file_args *a, int check_top) {
+    const int dtype = a->dtype, ntime = a->ntime, N = a->nlev, S = a->nplev;
+    const long long ncol = a->ncol, n2 = (long long)ntime * ncol;
+    const bool ref = a->ref_dtype != 0, local = a->local_p_ref != 0, lerp = (a->x_hi != 0.0);
+    const size_t es = (dtype == PGW_F64 || ref) ? 8 : 4;       // element size of the level arrays the loop produces
+    NEED(ctx, !ctx->reduce_fn, "latitude-band sharding needs the multi-pass loop (i_reinterp = 0)");
+    int rc;
+    void *evap = nullptr, *relhum = nullptr, *hur = a->hur_pgw_out, *state = nullptr;
+    const size_t field = (size_t)ntime * N * ncol * es;
+    if ((rc = ws_get(ctx, 0, field, &evap))) return rc;
+    if ((rc = ws_get(ctx, 2, field, &relhum))) return rc;
+    if (!hur && (rc = ws_get(ctx, 7, field, &hur))) return rc;
+    if ((rc = ws_get(ctx, 1, (size_t)n2 * 6 * sizeof(double), &state))) return rc;
+    double *phi_era = (double *)state, *dphi = phi_era + n2, *delta_ps = dphi + n2, *adj_ps = delta_ps + n2;
+    double *pref_f = adj_ps + n2;
+    int *pref_idx = (int *)(pref_f + n2);
+    Levels lv = levels_of(ctx);
+    const int full_column = ctx->opt[PGW_OPT_FULL_COLUMN];
+    const double zx_hi = a->per_var_time ? a->zg_x_hi : a->x_hi, zx_new = a->per_var_time ? a->zg_x_new : a->x_new;
+    PlevTable ptf;
+    memset(&ptf, 0, sizeof(ptf));
+    if (local) {
+        NEED(ctx, a->zg3_b != nullptr, "local_p_ref needs the full zg records (zg3_b / zg3_a)");
+        ptf.n = S;
+        for (int i = 0; i < S; ++i) ptf.p[i] = a->plev[i];
+    }
+    if ((rc = status_reset(ctx))) return rc;
+    // ---- ERA state: RELHUM (step_03:87-94)
+    {
+        Prof pr(ctx, PGW_K_Q_TO_RH);
+        if (ref) {
+            hipLaunchKernelGGL(k_relhum_ref, dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, lv, ntime, ncol,
+                               (const float *)a->QV, (const float *)a->PS, (const float *)a->T, (double *)relhum);
+        } else {
+            int vec = pick_vec(ctx, dtype, ncol, {a->QV, a->PS, a->T, relhum});
+            DISPATCH_TV(dtype, vec, hipLaunchKernelGGL((k_humidity_hybrid<T, V, 0>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                                        ctx->stream, lv, ntime, ncol, (const T *)a->QV, (const T *)a->PS,
+                                                        (const T *)a->T, (T *)relhum));
+        }
+    }
+    if (!local) {
+        // phi_ref of the ERA state (constant for a fixed p_ref; :280-287 recomputes it) and g * dzg (:292-295); zeroed state
+        launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, a->T, a->QV, a->PS, a->FIS, a->p_ref, phi_era, full_column, nullptr, ref);
+        DISPATCH_TLV(dtype, ref, 1, {
+            DeltaSrc<T> z{(const T *)a->zg_b, (zx_hi == 0.0) ? nullptr : (const T *)a->zg_a, zx_hi, zx_new};
+            hipLaunchKernelGGL((k_dphi_clim<T, REF>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2, z, CON_G, dphi,
+                               delta_ps, adj_ps);
+            (void)V;
+        });
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(delta_ps, 0, sizeof(double) * 2 * n2, ctx->stream));    // :182-184
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = status_check(ctx))) return rc;
+
+    // one pair of variables (ERA fields + deltas) onto the levels of ps_pgw; thermo: ta + hur with e, else ua + va
+    auto reinterp = [&](bool thermo) {
+        Prof pr(ctx, PGW_K_VERT_INTERP_DELTA);
+        const void *b0 = thermo ? a->ta_b : a->ua_b, *a0 = thermo ? a->ta_a : a->ua_a;
+        const void *b1 = thermo ? a->hur_b : a->va_b, *a1 = thermo ? a->hur_a : a->va_a;
+#define PGW_FILL_PAIR(rv)                                                                                                  \
+        rv.d[0] = DeltaSrc<T>{(const T *)b0, lerp ? (const T *)a0 : nullptr, a->x_hi, a->x_new};                           \
+        rv.d[1] = DeltaSrc<T>{(const T *)b1, lerp ? (const T *)a1 : nullptr, a->x_hi, a->x_new};                           \
+        rv.sfc[0] = DeltaSrc<T>{thermo ? (const T *)a->tas_b : nullptr, (thermo && lerp) ? (const T *)a->tas_a : nullptr, a->x_hi, a->x_new};   \
+        rv.sfc[1] = DeltaSrc<T>{thermo ? (const T *)a->hurs_b : nullptr, (thermo && lerp) ? (const T *)a->hurs_a : nullptr, a->x_hi, a->x_new}; \
+        DeltaSrc<T> p{(const T *)a->pshist_b, lerp ? (const T *)a->pshist_a : nullptr, a->x_hi, a->x_new};
+        if (ref) {
+            typedef float T;
+            if (thermo) {
+                ReinterpPair<float, float, double, double> rv;
+                PGW_FILL_PAIR(rv)
+                rv.era0 = (const float *)a->T; rv.era1 = (const double *)relhum;
+                rv.out[0] = (double *)a->T_out; rv.out[1] = (double *)hur; rv.evap = (double *)evap;
+                launch_reinterp_pair<float, float, double, double, true>(ctx, lv, ntime, S, ncol, rv, p, (const float *)a->PS,
+                                                                         (const float *)a->PS_out, true, check_top);
+            } else {
+                ReinterpPair<float, float, float, double> rv;
+                PGW_FILL_PAIR(rv)
+                rv.era0 = (const float *)a->U; rv.era1 = (const float *)a->V;
+                rv.out[0] = (double *)a->U_out; rv.out[1] = (double *)a->V_out; rv.evap = nullptr;
+                launch_reinterp_pair<float, float, float, double, true>(ctx, lv, ntime, S, ncol, rv, p, (const float *)a->PS,
+                                                                        (const float *)a->PS_out, false, check_top);
+            }
+        } else {
+            DISPATCH_T(dtype, {
+                ReinterpPair<T> rv;
+                PGW_FILL_PAIR(rv)
+                rv.era0 = (const T *)(thermo ? a->T : a->U); rv.era1 = (const T *)(thermo ? relhum : a->V);
+                rv.out[0] = (T *)(thermo ? a->T_out : a->U_out); rv.out[1] = (T *)(thermo ? hur : a->V_out);
+                rv.evap = thermo ? (T *)evap : nullptr;
+                launch_reinterp_pair<T>(ctx, lv, ntime, S, ncol, rv, p, (const T *)a->PS, (const T *)a->PS_out, thermo, check_top);
+            });
+        }
+#undef PGW_FILL_PAIR
+    };
+    auto top_check = [&]() -> int {                       // functions.py:417-425
+        if (!check_top) return PGW_OK;
+        DevStatus *h = ctx->h_status;
+        if (!h->nan_seen && h->min_targ_bits != ~0ull && h->min_src_bits != ~0ull) {
+            double mt, ms;
+            memcpy(&mt, &h->min_targ_bits, 8);
+            memcpy(&ms, &h->min_src_bits, 8);
+            if (mt < ms) { ctx->err = status_text(PGW_ERR_TOP_PRESSURE); ctx->err_col = -1; return PGW_ERR_TOP_PRESSURE; }
+        }
+        return PGW_OK;
+    };
+
+    double err = INFINITY;                                                  // :186
+    int it = 1;                                                             // :188
+    a->n_iter = 0;
+    for (int i = 0; i < 32; ++i) a->max_err_hist[i] = NAN;
+    while (err > a->thresh) {                                               // :189
+        if ((rc = status_reset(ctx))) return rc;
+        if (local) {
+            // delta_ps += adj_ps; the column's reference level (never lower than the last pass's); g * zg there   :192, 219-253, 292-295
+            DISPATCH_TLV(dtype, ref, 1, {
+                DeltaSrc<T> z{(const T *)a->zg3_b, (zx_hi == 0.0) ? nullptr : (const T *)a->zg3_a, zx_hi, zx_new};
+                hipLaunchKernelGGL((k_local_p_ref<T, REF>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, ptf, ctx->h_akN,
+                                   ctx->h_bkN, n2, (const T *)a->PS, delta_ps, adj_ps, z, ncol, it == 1 ? 1 : 0, pref_f,
+                                   pref_idx, dphi, ctx->d_status);
+                hipLaunchKernelGGL((k_update_ps<T, REF>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2,
+                                   (const T *)a->PS, delta_ps, adj_ps, (T *)a->PS_out, 0);                 // :193
+                (void)V;
+            });
+            launch_phi_ref_hybrid(ctx, dtype, ntime, ncol, a->T, a->QV, a->PS, a->FIS, 0.0, phi_era, full_column, pref_f, ref);   // :280-287
+        } else {
+            DISPATCH_TLV(dtype, ref, 1, {                                                                  // :192-193
+                hipLaunchKernelGGL((k_update_ps<T, REF>), dim3(nblocks(n2, BLOCK)), dim3(BLOCK), 0, ctx->stream, n2,
+                                   (const T *)a->PS, delta_ps, adj_ps, (T *)a->PS_out, 1);
+                (void)V;
+            });
+        }
+        reinterp(true);                                                     // :202-216 + e of functions.py:123
+        // :262-308 on the re-interpolated fields (delta_ps already carries this pass's increment)
+        launch_step(ctx, dtype, ntime, ncol, a->T_out, evap, a->PS, a->FIS, phi_era, dphi, delta_ps, adj_ps, a->p_ref,
+                    local ? pref_f : nullptr, a->adj_factor, full_column, 0, nullptr, nullptr, ref);
+        HIPCHK(ctx, hipGetLastError());
+        if ((rc = status_check(ctx))) return rc;
+        if ((rc = top_check())) return rc;
+        err = max_err_of(ctx);                                              // :308
+        if (it - 1 < 32) a->max_err_hist[it - 1] = err;
+        it += 1;                                                            // :313
+        if (it > a->max_n_iter) {                                           // :315-319
+            a->n_iter = it - 1;
+            ctx->err = status_text(PGW_ERR_NOT_CONVERGED);
+            ctx->err_col = -1;
+            return PGW_ERR_NOT_CONVERGED;
+        }
+    }
+    a->n_iter = it - 1;
+    a->passes_launched = it - 1;
+    a->levels_touched = 0;
+    if ((rc = status_reset(ctx))) return rc;
+    reinterp(false);                                                        // ua, va on the final levels   :330-343
+    {   // hus of the last pass (:262-266, 370) from its e; PS_out already holds ps_pgw of the last pass
+        int vec = pick_vec(ctx, dtype, ncol, {a->PS, evap, a->PS_out, a->QV_out, delta_ps});
+        Prof pr(ctx, PGW_K_FINALIZE);
+        DISPATCH_TLV(dtype, ref, vec, hipLaunchKernelGGL((k_finalize_ps_hus<T, TL, V, REF>), dim3(nblocks(n2 / V, BLOCK)), dim3(BLOCK), 0,
+                                                         ctx->stream, lv, ntime, ncol, (const T *)a->PS, delta_ps, (const TL *)evap,
+                                                         (T *)a->PS_out, (TL *)a->QV_out, 0));
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if ((rc = status_check(ctx))) return rc;
+    return top_check();
+}
+
 // ------------------------------------------------------------------ whole file
 static int step03_file(pgw_ctx *ctx, pgw_file_args *a);
 
@@ -1413,6 +1590,11 @@ static int step03_file(pgw_ctx *ctx, pgw_file_args *a) {
                                (T *)a->T_SO_out);
             (void)V;
         });
+    }
+
+    if (a->i_reinterp) {                                  // settings.i_reinterp = 1: the loop re-interpolates in every pass
+        a->levels_touched = 0; a->passes_launched = 0;
+        return run_reinterp_file(ctx, a, check_top);
     }
 
     // ---- ta + hur -> T_pgw, e_pgw   and   ua + va -> U_pgw, V_pgw

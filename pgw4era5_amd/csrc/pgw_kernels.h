@@ -136,6 +136,26 @@ __global__ __launch_bounds__(BLOCK) void k_humidity_leaf(long long n, const T *_
     }
 }
 
+// RELHUM of a float32 ERA state in reference-dtype mode (step_03:91-94 on a float32 file): float32 QV, T, PS in, the float64
+// field numpy's promotion produces out (q_to_rh_f32: float64 pressure, float32 e_sat chain)
+__global__ __launch_bounds__(BLOCK) void k_relhum_ref(Levels lv, int ntime, long long ncol, const float *__restrict__ hus,
+                                                      const float *__restrict__ ps, const float *__restrict__ ta,
+                                                      double *__restrict__ out) {
+    __shared__ double s_lev[LEVTAB_DOUBLES];
+    LevTab lt = stage_levels<false, true>(lv, s_lev, BLOCK);
+    long long g = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= (long long)ntime * ncol) return;
+    const long long t = g / ncol, c = g - t * ncol;
+    const double p = (double)ps[g];
+    const int N = lv.nlev;
+    const long long base = t * N * ncol + c;
+#pragma unroll 4
+    for (int l = 0; l < N; ++l) {
+        const long long o = base + (long long)l * ncol;
+        out[o] = q_to_rh_f32(hus[o], lt.akm[l] + p * lt.bkm[l], ta[o]);
+    }
+}
+
 // same with pa = akm + ps*bkm rebuilt in registers (no 4-D pressure array)
 template <typename T, int V, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_humidity_hybrid(Levels lv, int ntime, long long ncol,
@@ -1007,12 +1027,16 @@ __global__ __launch_bounds__(BLOCK) void k_reinterp_field(PlevTable pt, Levels l
 // the load it copies, so each level exposes a full memory latency (2 TB/s).  Here the loads are consumed by the ring
 // writes in issue order with four rows in flight, and the window's `while` loop only touches LDS.  A window position the
 // ring does not hold (the two surface pressures more than 3-4 levels apart, or a restart) reads global memory directly.
-template <typename T>
+// T: storage type of the delta records and the surface pressures; TE0 / TE1: of the two ERA fields; TO: of the outputs.
+// All equal except in reference-dtype mode on float32 files (T = float): the ERA temperature is the file's float32, RELHUM
+// of the ERA state is float64 (functions.py:58-116 with a float64 pressure), and `era + delta` is float64 (step_03:209-216).
+template <typename T, typename TE0 = T, typename TE1 = T, typename TO = T>
 struct ReinterpPair {
     DeltaSrc<T> d[2], sfc[2];
-    const T *era[2];
-    T *out[2];
-    T *evap;               // EVAP: the vapour pressure of (out[1], out[0]) = (hur_pgw, ta_pgw), what the loop pass reads
+    const TE0 *era0;
+    const TE1 *era1;
+    TO *out[2];
+    TO *evap;              // EVAP: the vapour pressure of (out[1], out[0]) = (hur_pgw, ta_pgw), what the loop pass reads
 };
 constexpr int RING = 8, RING_LEAD = 4;
 
@@ -1026,8 +1050,13 @@ constexpr int RING = 8, RING_LEAD = 4;
 // EVAP (ta + hur inside the loop): also writes e = hur_pgw / 100 * e_sat(ta_pgw) (functions.py:123) of the STORED values,
 // the iterate-independent half of relative_to_specific_humidity that k_adjust_ps_step reads - the bits of a separate
 // k_humidity_hybrid<.., 2> pass over the two outputs, without reading them back
-template <typename T, bool HAS_SFC, typename O, bool EVAP = false>
-__global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol, ReinterpPair<T> rv,
+// REF (reference-dtype mode): the roundings numpy / numba put into the reference on float32 files - the record difference of
+// the time interpolation in float32 (DeltaSrc::get<REF>), numba's `src_y[i2] - src_y[i1]` of interp_extrap_1d in the dtype
+// of the source (float32 for an ERA field of the file, float64 for RELHUM; for the deltas float32 only when the instant is
+// a record, functions.py:282-283, 575-578), everything else float64.
+template <typename T, bool HAS_SFC, typename O, bool EVAP = false, typename TE0 = T, typename TE1 = T, typename TO = T, bool REF = false>
+__global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_reinterp_pair(PlevTable pt, Levels lv, int ntime, long long ncol,
+                                                            ReinterpPair<T, TE0, TE1, TO> rv,
                                                             DeltaSrc<T> psh, const T *__restrict__ ps_era,
                                                             const T *__restrict__ ps_pgw, int check_top, DevStatus *st) {
     extern __shared__ double lds_rp[];               // akm[N] | bkm[N]
@@ -1035,7 +1064,8 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
     __shared__ int s_nan[BLOCK / 64];
     __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
     __shared__ double s_logt[2 * LOG_TABLE_N];
-    __shared__ T s_ring[2][RING][BLOCK];
+    __shared__ TE0 s_ring0[RING][BLOCK];
+    __shared__ TE1 s_ring1[RING][BLOCK];
     const int S = pt.n, N = lv.nlev;
     double *s_akm = lds_rp, *s_bkm = lds_rp + N;
     stage_log_table(s_logt, BLOCK);
@@ -1057,9 +1087,9 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
         double d_sfc0 = 0.0, d_sfc1 = 0.0, lnps = 0.0, pshv = 0.0;
         if (HAS_SFC) {
             bool bad = false;
-            pshv = psh.get(flat);
-            d_sfc0 = rv.sfc[0].get(flat);
-            d_sfc1 = rv.sfc[1].get(flat);
+            pshv = psh.template get<REF>(flat);
+            d_sfc0 = rv.sfc[0].template get<REF>(flat);
+            d_sfc1 = rv.sfc[1].template get<REF>(flat);
             if (pshv > pt.pmax) {                                  // functions.py:356-359
                 ksfc = S - 1;
             } else if (pshv < pt.pmin) {                           // :360-361
@@ -1088,8 +1118,13 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
         const SharedDivisor by_x_hi(lerp ? rv.d[0].x_hi : 1.0);
         auto tl = [&](T rb, T ra) -> double {             // DeltaSrc::get (functions.py:282-292)
             if (!lerp) return (double)rb;
-            return by_x_hi.divide((double)ra - (double)rb) * x_new + (double)rb;
+            const double diff = REF ? (double)(T)(ra - rb) : (double)ra - (double)rb;
+            return by_x_hi.divide(diff) * x_new + (double)rb;
         };
+        // value differences of the column interpolations (functions.py:575-578) in the dtype numba sees them in
+        auto ydiff = [&](double hi, double lo) -> double { return (REF && !lerp) ? (double)((float)hi - (float)lo) : hi - lo; };
+        auto ediff0 = [](double hi, double lo) -> double { return (REF && sizeof(TE0) == 4) ? (double)((float)hi - (float)lo) : hi - lo; };
+        auto ediff1 = [](double hi, double lo) -> double { return (REF && sizeof(TE1) == 4) ? (double)((float)hi - (float)lo) : hi - lo; };
         auto fetch = [&](int i1) {
             if (ci == i1) return;
             const int ih = (i1 + 1 < S) ? i1 + 1 : i1;
@@ -1110,25 +1145,34 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
             ci = i1;
         };
         const double pse = (double)ps_era[flat], psv = (double)ps_pgw[flat];
-        const O obase = (O)((unsigned long long)(t * (long long)N * ncol + c) * sizeof(T));
-        const T *pf0 = rv.era[0], *pf1 = rv.era[1];
-        auto lev_off = [&](int lev) -> O { return obase + (O)(lev < N ? lev : N - 1) * row; };
+        // byte offsets of the level arrays in units of the first ERA field's element; the other field and the outputs scale
+        // them by the ratio of the element sizes (1 unless the types differ: reference-dtype mode)
+        const O erow = (O)((unsigned long long)ncol * sizeof(TE0));
+        const O obase = (O)((unsigned long long)(t * (long long)N * ncol + c) * sizeof(TE0));
+        static_assert(sizeof(TE1) % sizeof(TE0) == 0 && sizeof(TO) % sizeof(TE0) == 0, "element sizes");
+        auto off1 = [](O o) -> O { return o * (O)(sizeof(TE1) / sizeof(TE0)); };
+        auto offo = [](O o) -> O { return o * (O)(sizeof(TO) / sizeof(TE0)); };
+        const TE0 *pf0 = rv.era0;
+        const TE1 *pf1 = rv.era1;
+        auto lev_off = [&](int lev) -> O { return obase + (O)(lev < N ? lev : N - 1) * erow; };
         // ---- the ring: at target level l it holds the ERA levels [l - 3, l + 5)
         const int tid = threadIdx.x;
         int ring_lo = 0;                                               // l - 3 (may be negative)
         auto era_at = [&](int lev, double &u, double &v) {
-            if ((unsigned)(lev - ring_lo) < (unsigned)RING) { u = (double)s_ring[0][lev & (RING - 1)][tid]; v = (double)s_ring[1][lev & (RING - 1)][tid]; }
-            else { const O o = lev_off(lev); u = (double)ld_off(pf0, o); v = (double)ld_off(pf1, o); }
+            if ((unsigned)(lev - ring_lo) < (unsigned)RING) { u = (double)s_ring0[lev & (RING - 1)][tid]; v = (double)s_ring1[lev & (RING - 1)][tid]; }
+            else { const O o = lev_off(lev); u = (double)ld_off(pf0, o); v = (double)ld_off(pf1, off1(o)); }
         };
-        T na[RING_LEAD], nb[RING_LEAD];                                 // rows in flight: levels l + 4 .. l + 7 at the top of level l
+        TE0 na[RING_LEAD];                                              // rows in flight: levels l + 4 .. l + 7 at the top of level l
+        TE1 nb[RING_LEAD];
         {
-            T ia[RING_LEAD], ib[RING_LEAD];
+            TE0 ia[RING_LEAD];
+            TE1 ib[RING_LEAD];
 #pragma unroll
-            for (int u = 0; u < RING_LEAD; ++u) { ia[u] = ld_off_nt(pf0, lev_off(u)); ib[u] = ld_off_nt(pf1, lev_off(u)); }
+            for (int u = 0; u < RING_LEAD; ++u) { ia[u] = ld_off_nt(pf0, lev_off(u)); ib[u] = ld_off_nt(pf1, off1(lev_off(u))); }
 #pragma unroll
-            for (int u = 0; u < RING_LEAD; ++u) { na[u] = ld_off_nt(pf0, lev_off(RING_LEAD + u)); nb[u] = ld_off_nt(pf1, lev_off(RING_LEAD + u)); }
+            for (int u = 0; u < RING_LEAD; ++u) { na[u] = ld_off_nt(pf0, lev_off(RING_LEAD + u)); nb[u] = ld_off_nt(pf1, off1(lev_off(RING_LEAD + u))); }
 #pragma unroll
-            for (int u = 0; u < RING_LEAD; ++u) { s_ring[0][u][tid] = ia[u]; s_ring[1][u][tid] = ib[u]; }
+            for (int u = 0; u < RING_LEAD; ++u) { s_ring0[u][tid] = ia[u]; s_ring1[u][tid] = ib[u]; }
         }
         // ---- window over the source axis: level wj - 1 (wxm, um, vm) and level wj (wxj, uj, vj)
         int wj;
@@ -1149,10 +1193,10 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
                 const int l = l0 + u;
                 if (l < N) {
                     // row l + 4 into the ring (it replaces level l - 4), row l + 8 requested
-                    s_ring[0][(l + RING_LEAD) & (RING - 1)][tid] = na[u];
-                    s_ring[1][(l + RING_LEAD) & (RING - 1)][tid] = nb[u];
+                    s_ring0[(l + RING_LEAD) & (RING - 1)][tid] = na[u];
+                    s_ring1[(l + RING_LEAD) & (RING - 1)][tid] = nb[u];
                     ring_lo = l + RING_LEAD + 1 - RING;
-                    { const O o = lev_off(l + 2 * RING_LEAD); na[u] = ld_off_nt(pf0, o); nb[u] = ld_off_nt(pf1, o); }
+                    { const O o = lev_off(l + 2 * RING_LEAD); na[u] = ld_off_nt(pf0, o); nb[u] = ld_off_nt(pf1, off1(o)); }
                     if (l == 0) wreset();
                     const double p = s_akm[l] + psv * s_bkm[l];                                 // step_03:196-197
                     if (check_top) { if (p != p) nanflag |= 1; else min_t = fmin(min_t, p); }
@@ -1173,8 +1217,8 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
                     else {                                                  // :575-578
                         if (wdiv != wj) { by_W = SharedDivisor(wxj - wxm); wdiv = wj; }
                         const double dx = x - wxm;
-                        e0 = um + by_W.divide(dx * (uj - um));
-                        e1 = vm + by_W.divide(dx * (vj - vm));
+                        e0 = um + by_W.divide(dx * ediff0(uj, um));
+                        e1 = vm + by_W.divide(dx * ediff1(vj, vm));
                     }
                     // -- the climate deltas at this pressure (as k_vert_interp_delta)
                     while (j < S) {
@@ -1196,14 +1240,14 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
                         if (ddiv != i1) { dx1 = srcx(i1); by_D = SharedDivisor(srcx(i2) - dx1); ddiv = i1; }   // once per delta bracket
                         const double x1 = dx1;
                         const double dx = x - x1;
-                        y0 = a_lo + by_D.divide(dx * (a_hi - a_lo));
-                        y1 = b_lo + by_D.divide(dx * (b_hi - b_lo));
+                        y0 = a_lo + by_D.divide(dx * ydiff(a_hi, a_lo));
+                        y1 = b_lo + by_D.divide(dx * ydiff(b_hi, b_lo));
                     }
-                    const O o = obase + (O)l * row;
-                    const T r0 = (T)(e0 + y0), r1 = (T)(e1 + y1);                               // vars_era + deltas  :216
+                    const O o = offo(obase + (O)l * erow);
+                    const TO r0 = (TO)(e0 + y0), r1 = (TO)(e1 + y1);                             // vars_era + deltas  :216
                     st_off_nt(rv.out[0], o, r0);
                     st_off_nt(rv.out[1], o, r1);
-                    if (EVAP) st_off(rv.evap, o, (T)rh_to_e((double)r1, (double)r0));
+                    if (EVAP) st_off(rv.evap, o, (TO)rh_to_e((double)r1, (double)r0));
                     xprev = (x == x) ? x : __builtin_inf();
                 }
             }
@@ -2092,15 +2136,16 @@ __global__ __launch_bounds__(BLOCK) void k_local_p_ref(PlevTable pt /* p[] in FI
     dphi[i] = zg.template get<REF>((t * pt.n + k) * ncol + c) * CON_G;            // step_03:292-295
 }
 
-// step_03:192-193
-template <typename T>
+// step_03:192-193.  apply_adj = 0: delta_ps already carries this pass's increment (k_local_p_ref applied it), only
+// ps_pgw = PS + delta_ps is formed.  REF: the float32 sums of the reference on float32 files (next_delta_ps, ps_of).
+template <typename T, bool REF = false>
 __global__ __launch_bounds__(BLOCK) void k_update_ps(long long n, const T *__restrict__ PS, double *__restrict__ delta_ps,
-                                                     const double *__restrict__ adj_ps, T *__restrict__ ps_out) {
+                                                     const double *__restrict__ adj_ps, T *__restrict__ ps_out, int apply_adj = 1) {
     long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
-    double d = delta_ps[i] + adj_ps[i];
-    delta_ps[i] = d;
-    ps_out[i] = (T)((double)PS[i] + d);
+    double d = delta_ps[i];
+    if (apply_adj) { d = next_delta_ps<REF>(d, adj_ps[i]); delta_ps[i] = d; }
+    ps_out[i] = (T)ps_of<REF>((double)PS[i], d);
 }
 
 // g * time-interpolated zg delta at p_ref -> fp64 loop constant (step_03:292-295)

@@ -263,7 +263,7 @@ def ref_dtype_mode(dtype, ref_dtype=None):
 
 
 def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error=False,
-                        p_ref=None, out=None, keep_hur=False, ref_dtype=None):
+                        p_ref=None, out=None, keep_hur=False, ref_dtype=None, i_reinterp=False):
     """The per-file compute path of pgw_for_era5 (reference step_03:62-346, i_reinterp = 0,
     fixed p_ref) on device arrays: ONE call into the C-ABI (`pgw_step03_file`).
 
@@ -271,7 +271,10 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     (1,N,nlat,nlon); T_SO (1,nsoil,nlat,nlon).  coeffs: dict ak,bk,[akm,bkm],soil1 (host).
     deltas: DeltaSet.  out: optional dict of preallocated output DeviceArrays (reused
     across files).  ref_dtype (float32 storage only; default settings.f32_file_mode): reference-dtype mode, T, QV, U, V
-    come back as float64 arrays like the reference's `era + delta`.  Returns (dict of DeviceArrays, info)."""
+    come back as float64 arrays like the reference's `era + delta`.  i_reinterp: settings.i_reinterp = 1 (step_03:202-216,
+    330-343: ta / hur and their deltas re-interpolated onto the current levels in every pass, ua / va after convergence) - the
+    same call with `pgw_file_args.i_reinterp` set, every combination with the reference level and the storage modes.
+    Returns (dict of DeviceArrays, info)."""
     lib, h = ctx.lib, ctx.handle
     if p_ref is None:
         p_ref = S.p_ref_inp
@@ -297,6 +300,7 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
     plev = deltas.plev
     a = _lib.FileArgs()
     a.per_var_time = 1                                              # every delta file is bracketed on its own time axis
+    a.i_reinterp = 1 if i_reinterp else 0
     zb, za, a.zg_x_hi, a.zg_x_new = deltas.pair('zg', target_dt, buf)
     if local_p_ref:
         if len(deltas.plev_zg) != len(plev) or np.any(deltas.plev_zg != plev):
@@ -356,16 +360,22 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
 
 
 def process_file_device_reinterp(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error=False,
-                                 p_ref=None, out=None):
-    """settings.i_reinterp = 1 (reference step_03:202-216, 330-343): in every pass the ERA ta / hur
-    fields and their deltas are re-interpolated onto the CURRENT model-level pressures, ua / va once
-    after convergence.  Composed from the function-level C-ABI entries (pressure_levels,
-    interp_logp_4d 'constant', vert_interp_delta, adjust_ps_step); the loop control is the reference's.
-    Same inputs / outputs as process_file_device (fixed p_ref only)."""
+                                 p_ref=None, out=None, ref_dtype=None, keep_hur=True):
+    """settings.i_reinterp = 1 (reference step_03:202-216, 330-343): process_file_device with `i_reinterp` - ONE call into
+    the C-ABI; fixed or local reference level, float64 / float32 files, reference-dtype mode."""
+    return process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error, p_ref=p_ref, out=out,
+                               keep_hur=keep_hur, ref_dtype=ref_dtype, i_reinterp=True)
+
+
+def process_file_device_reinterp_composed(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure_error=False,
+                                          p_ref=None, out=None):
+    """The same path composed on the host from the function-level C-ABI entries (pgw_reinterp_pass per pass,
+    pgw_reinterp_pair for ua / va, the humidity entries) - round 2's form, fixed p_ref, float64 arithmetic on the storage
+    type; kept as an independent composition the one-call path is tested against bit for bit."""
     lib, h = ctx.lib, ctx.handle
     p_ref = S.p_ref_inp if p_ref is None else p_ref
     if p_ref is None or p_ref == 'local':
-        raise NotImplementedError('i_reinterp = 1 together with p_ref_inp = None is not built')
+        raise NotImplementedError('the host-composed form knows the fixed reference level only')
     dt = deltas.dtype
     tag = dtype_tag(dt)
     ctx.set_levels(coeffs['ak'], coeffs['bk'], coeffs.get('akm'), coeffs.get('bkm'))
@@ -515,7 +525,8 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
             ctx.band_abort()
         raise
     if i_reinterp:
-        out, info = process_file_device_reinterp(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref)
+        out, info = process_file_device_reinterp(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref,
+                                                 ref_dtype=ref_dtype)
     else:
         out, info = process_file_device(ctx, e, coeffs, ds, target_dt, ignore_top_pressure_error, p_ref, keep_hur=True,
                                         ref_dtype=ref_dtype)
@@ -749,10 +760,10 @@ def _stage_compute(item):
     except BaseException:
         sets.inp.put(inp)
         raise
-    run = process_file_device_reinterp if S.i_reinterp else process_file_device
     try:
-        out, info = run(ctx, inp, item['coeffs'], item['deltas'], item['era_step_dt'], item['ignore_top'],
-                        p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=out_set)
+        out, info = process_file_device(ctx, inp, item['coeffs'], item['deltas'], item['era_step_dt'], item['ignore_top'],
+                                        p_ref='local' if S.p_ref_inp is None else S.p_ref_inp, out=out_set,
+                                        i_reinterp=bool(S.i_reinterp))
         ctx.sync()                                          # outputs complete before the 'd2h' stream reads them
     except ValueError as e:
         sets.out.put(out_set)

@@ -145,6 +145,37 @@ def test_step03_daily_deltas_through_the_record_window(tmp_path, monkeypatch):
         assert open(os.path.join(out_dir, name), 'rb').read() == open(os.path.join(outs['1'][0], name), 'rb').read()
 
 
+@pytest.mark.parametrize('p_ref_inp', [30000, None])
+def test_step03_cli_with_i_reinterp_on_float32_files(files, monkeypatch, p_ref_inp):
+    """settings.i_reinterp = 1 through the command line on float32 files - with the fixed reference level and with
+    settings.p_ref_inp = None, independent switches in the reference (step_03_apply_to_era.py:202-253; settings.py:134-150) -
+    in the driver's default reference-dtype mode: T, QV, U, V written as float64 like the reference's `era + delta`, every
+    file against the reference-dtype oracle's re-interpolating loop with its own pass count."""
+    from pgw4era5_amd import step_03_apply_to_era as s3, ncio, settings as S
+    root, cases = files
+    monkeypatch.setattr(S, 'i_reinterp', 1)
+    monkeypatch.setattr(S, 'p_ref_inp', p_ref_inp)
+    out_dir = str(root / ('out_reinterp_%s' % p_ref_inp))
+    n_iters = s3._cli(['-i', str(root / 'era'), '-o', out_dir, '-d', str(root / 'deltas'),
+                       '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '1', '-t'])
+    for c, n in zip(cases, n_iters):
+        want = R.pgw_for_era5_arrays_reinterp(c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True,
+                                              p_ref=None if p_ref_inp is None else float(p_ref_inp))
+        base = _oracle(c)
+        assert n == want['n_iter']
+        ds = ncio.open_dataset(os.path.join(out_dir, 'cas{:%Y%m%d%H}0000.nc'.format(c['target_dt'])), decode_times=False)
+        assert ds['PS'].values.dtype == np.float32 and ds['T'].values.dtype == np.float64 and ds['U'].values.dtype == np.float64
+        np.testing.assert_allclose(ds['PS'].values, want['PS'], rtol=2.5e-7, err_msg='PS')
+        np.testing.assert_allclose(ds['T'].values, want['T'], rtol=2e-8, err_msg='T')
+        for k in ('U', 'V'):
+            np.testing.assert_allclose(ds[k].values, want[k], rtol=0, atol=2e-5, err_msg=k)
+        scale = np.nanmax(np.abs(want['QV']), axis=(2, 3), keepdims=True)
+        assert np.nanmax(np.abs(ds['QV'].values - want['QV']) / scale) < 6e-7
+        for k in ('T_SKIN', 'T_SO', 'FR_SEA_ICE'):                              # the surface riders do not depend on the mode
+            np.testing.assert_allclose(ds[k].values, base[k], rtol=1.3e-7, atol=0, equal_nan=True, err_msg=k)
+        assert np.abs(ds['T'].values - base['T']).max() > 1e-6                  # not the default mode's field
+
+
 def test_step03_non_convergence_names_the_file(files, monkeypatch):
     """step_03_apply_to_era.py:315-319: the error names the input file and the setting to raise."""
     from pgw4era5_amd import step_03_apply_to_era as s3, settings as S

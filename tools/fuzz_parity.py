@@ -27,7 +27,7 @@ def one(rng, i, run=True, debug=False):
     nlat, nlon = int(rng.integers(1, 10)), int(rng.integers(1, 14))
     nlev = int(rng.integers(8, 45))
     dtype = np.float32 if rng.random() < 0.5 else np.float64
-    mode = rng.choice(['file', 'file', 'file', 'local', 'reinterp'])
+    mode = rng.choice(['file', 'file', 'file', 'local', 'reinterp', 'reinterp_local'])
     # plev subset that keeps p_ref = 30000 Pa and the top / bottom levels
     keep = np.ones(len(synthetic.PLEV19), dtype=bool)
     if rng.random() < 0.4:
@@ -72,10 +72,15 @@ def one(rng, i, run=True, debug=False):
     desc = dict(i=i, shape=[nlat, nlon, nlev], dtype=np.dtype(dtype).name, mode=str(mode), S=int(len(plev)), target=str(c['target_dt']),
                 inject=inject)
     try:
-        if mode == 'reinterp':
-            got = s3.pgw_for_era5_arrays(*args, i_reinterp=True)
-            want = O.pgw_for_era5_arrays_reinterp(c['era'], {k: np.asarray(v, dtype=np.float64) for k, v in d.items()}, *args[2:])
-            tol = dict(PS=1e-9, T=1e-9, QV=1e-9) if dtype == np.float64 else dict(PS=2e-6, T=2e-6, QV=5e-6)
+        if mode in ('reinterp', 'reinterp_local'):
+            pr = None if mode == 'reinterp_local' else 30000.0
+            got = s3.pgw_for_era5_arrays(*args, i_reinterp=True, p_ref='local' if pr is None else None)
+            if dtype == np.float32:                       # reference-dtype mode (the default on float32 files)
+                want = R.pgw_for_era5_arrays_reinterp(*args, p_ref=pr)
+                tol = dict(PS=2.5e-7, T=2e-8, QV=6e-7)
+            else:
+                want = O.pgw_for_era5_arrays_reinterp(c['era'], {k: np.asarray(v, dtype=np.float64) for k, v in d.items()}, *args[2:], p_ref=pr)
+                tol = dict(PS=1e-9, T=1e-9, QV=1e-9)
         elif mode == 'local':
             got = s3.pgw_for_era5_arrays(*args, p_ref='local', ref_dtype=False)
             f64 = lambda x: np.asarray(x, dtype=np.float64)
@@ -105,7 +110,10 @@ def one(rng, i, run=True, debug=False):
         if mode == 'local':
             return desc, 'both raise: %s (local mode: the oracle side raised or the HIP side did)' % type(e).__name__
         try:
-            (O.pgw_for_era5_arrays_reinterp if mode == 'reinterp' else (R if dtype == np.float32 else O).pgw_for_era5_arrays)(*args)
+            if mode in ('reinterp', 'reinterp_local'):
+                (R if dtype == np.float32 else O).pgw_for_era5_arrays_reinterp(*args, p_ref=None if mode == 'reinterp_local' else 30000.0)
+            else:
+                (R if dtype == np.float32 else O).pgw_for_era5_arrays(*args)
         except Exception as e2:                         # noqa: BLE001
             same = type(e) is type(e2) and (str(e) == str(e2) or not str(e2) or str(e).startswith(str(e2).rstrip('.!')[:40]))
             return desc, ('both raise: %s' % type(e).__name__) if same else \
@@ -121,7 +129,7 @@ def one(rng, i, run=True, debug=False):
         dd = float(np.nanmax(np.abs(got[k] - want[k]) / np.maximum(np.abs(want[k]), 1.0)))
         # i_reinterp on a float32 file: ps_pgw is held in float32 (as in the reference), the oracle's is float64; the
         # 4e-8 relative pressure shift times the white-noise vertical gradient of the synthetic winds is ~1e-5 m/s
-        lim = 1e-4 if (mode == 'reinterp' and dtype == np.float32) else max(tol['T'], 1e-9)
+        lim = 1e-4 if (mode in ('reinterp', 'reinterp_local') and dtype == np.float32 and k != 'T') else max(tol['T'], 1e-9)
         if not dd <= lim:
             bad.append('%s %.3e' % (k, dd))
     dq = scaled(got['QV'], want['QV'])
