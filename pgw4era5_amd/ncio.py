@@ -328,7 +328,18 @@ def _pread_into(fd, buf, offset):
         mv = mv[n:]
 
 
-def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, decode_mask_scale=None):
+def placeholder(shape, dtype):
+    """An array of the given shape and dtype that owns one element (all strides 0): stands for a variable whose data are
+    read or written elsewhere (band-wise I/O) wherever only shape and dtype matter - the header of to_netcdf's layout."""
+    return np.lib.stride_tricks.as_strided(np.zeros(1, dtype=dtype), shape=tuple(int(n) for n in shape),
+                                           strides=(0,) * len(shape), writeable=False)
+
+
+def is_placeholder(a):
+    return isinstance(a, np.ndarray) and a.size > 1 and all(st == 0 for st in a.strides)
+
+
+def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, decode_mask_scale=None, skip=()):
     """Read a NetCDF-3 file completely into memory (`xr.open_dataset(...).load()`).
     decode_times=False corresponds to the reference's `decode_cf=False` (step_03:60: the ERA5 file is taken raw);
     the default decodes like a plain `xr.open_dataset` (the delta files, functions.py:203): CF times AND
@@ -338,7 +349,9 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, 
     layout in place.  With `raw_big=True` variables of at least BIG_VARIABLE bytes are NOT converted: their
     `.values` keep the big-endian dtype of the file ('>f4'), for `DeviceArray.copy_from` to convert on the GPU;
     `alloc(nbytes) -> writable uint8 array` supplies their buffers (pinned host memory in the step_03 driver).
-    PGW_NC_READER=scipy selects the previous reader built on scipy.io.netcdf_file."""
+    PGW_NC_READER=scipy selects the previous reader built on scipy.io.netcdf_file.
+    skip: names of variables NOT to read - they come back as placeholders of the right shape and dtype (band-wise I/O:
+    every rank reads only its latitude rows of the large fields, read_band)."""
     import os
     from concurrent.futures import ThreadPoolExecutor
     if decode_mask_scale is None:
@@ -357,6 +370,8 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, 
             dt = v['dtype']
             nrec = hdr['numrecs'] if v['record'] else 1
             total = v['nbytes'] * nrec
+            if v['name'] in skip:                                # data taken elsewhere (read_band): shape and dtype only
+                return placeholder(v['shape'], dt)
             big = total >= BIG_VARIABLE
             if big and alloc is not None:
                 buf = alloc(total)[:total]
@@ -385,7 +400,8 @@ def open_dataset(path, decode_times=True, threads=4, raw_big=False, alloc=None, 
     ds = Dataset(attrs=hdr['attrs'], record_dim=rec_dims[0] if rec_dims else None)
     if decode_mask_scale:
         for v in hdr['vars']:
-            data[v['name']], v['attrs'] = mask_and_scale(data[v['name']], v['attrs'])
+            if v['name'] not in skip:
+                data[v['name']], v['attrs'] = mask_and_scale(data[v['name']], v['attrs'])
     coords = {}
     for v in hdr['vars']:
         if v['dims'] == (v['name'],):
@@ -603,22 +619,9 @@ def _nc_header(attrs, dims, record_dim, numrecs, specs, begins, dim_ids):
     return h
 
 
-def to_netcdf(ds, path, threads=None):
-    """Write a Dataset as NetCDF-3 64-bit-offset (`.to_netcdf(path, mode='w')`, step_03:378).
-
-    Native writer (the classic format is a header + big-endian arrays): every variable is byte-swapped in one pass (not
-    at all if it is already big-endian) and written with `os.pwrite` at its offset, large variables in 64 MiB pieces on
-    `threads` threads - scipy's writer makes three copies of every array under the GIL and was the bottleneck of the
-    whole command line (1.06 s per 2.3 GB file; PGW_NC_WRITER=scipy selects it).
-    `ds.record_dim` (set by open_dataset from the input file's unlimited dimension): variables whose first dimension it
-    is are written as record variables - dimension length 0 in the header, `numrecs` records interleaved after the
-    fixed-size variables - so the ERA5 file keeps its unlimited `time` like the reference's `to_netcdf` does."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-    if os.environ.get('PGW_NC_WRITER') == 'scipy':
-        return _to_netcdf_scipy(ds, path)
-    if threads is None:
-        threads = int(os.environ.get('PGW_NC_WRITE_THREADS', '8'))
+def _plan(ds):
+    """Layout of a Dataset as a NetCDF-3 64-bit-offset file: (header bytes, specs, begins, total size, recsize, numrecs).
+    Only shapes and dtypes are looked at (placeholders do)."""
     dims = {}
     for f in ds.variables.values():
         for d, n in zip(f.dims, f.shape):
@@ -670,12 +673,34 @@ def to_netcdf(ds, path, threads=None):
     begins, total = layout(hlen)
     hdr = _nc_header(ds.attrs, dims, record_dim, numrecs, specs, begins, dim_ids)
     assert len(hdr) == hlen
+    return hdr, specs, begins, total, recsize, numrecs
+
+
+def to_netcdf(ds, path, threads=None, skip=()):
+    """Write a Dataset as NetCDF-3 64-bit-offset (`.to_netcdf(path, mode='w')`, step_03:378).
+
+    Native writer (the classic format is a header + big-endian arrays): every variable is byte-swapped in one pass (not
+    at all if it is already big-endian) and written with `os.pwrite` at its offset, large variables in 64 MiB pieces on
+    `threads` threads - scipy's writer makes three copies of every array under the GIL and was the bottleneck of the
+    whole command line (1.06 s per 2.3 GB file; PGW_NC_WRITER=scipy selects it).
+    `ds.record_dim` (set by open_dataset from the input file's unlimited dimension): variables whose first dimension it
+    is are written as record variables - dimension length 0 in the header, `numrecs` records interleaved after the
+    fixed-size variables - so the ERA5 file keeps its unlimited `time` like the reference's `to_netcdf` does.
+    skip: variables whose space is laid out (header, file size) but whose data are NOT written here (placeholders allowed):
+    the ranks of a band-wise run write their latitude rows of them (BandedWriter)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    if os.environ.get('PGW_NC_WRITER') == 'scipy' and not skip:
+        return _to_netcdf_scipy(ds, path)
+    if threads is None:
+        threads = int(os.environ.get('PGW_NC_WRITE_THREADS', '8'))
+    hdr, specs, begins, total, recsize, numrecs = _plan(ds)
     fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     try:
         os.ftruncate(fd, total)
         os.pwrite(fd, hdr, 0)
         CH = 64 << 20                                            # swap + write in 64 MiB pieces
-        flats = [np.ascontiguousarray(sp['data']).reshape(-1) for sp in specs]
+        flats = [None if sp['name'] in skip else np.ascontiguousarray(sp['data']).reshape(-1) for sp in specs]
 
         def write_piece(task):
             i, s0, s1, pos = task
@@ -691,6 +716,8 @@ def to_netcdf(ds, path, threads=None):
 
         tasks, small = [], []
         for i, sp in enumerate(specs):
+            if flats[i] is None:
+                continue
             item = flats[i].dtype.itemsize
             if sp['record']:                                     # record r of the variable starts at begin + r * recsize
                 n_el = sp['per'] // item
@@ -715,6 +742,100 @@ def to_netcdf(ds, path, threads=None):
             write_piece(t)
     finally:
         os.close(fd)
+
+
+# ------------------------------------------------------------------------------ band-wise I/O (latency mode)
+# One ERA5 file over several ranks in latitude bands: every rank reads and writes only its
+# rows of the fields.  In the classic layout a variable (..., lat, lon) is C-ordered, so rows [j0, j1) of one (time, level)
+# plane are ONE contiguous byte range: a band is one pread / pwrite per plane.
+def _band_ranges(v, recsize, numrecs, j0, j1, lat_axis):
+    """(outer index tuple, file offset, byte count) of the rows [j0, j1) of every plane of a variable described by a
+    header entry `v` (shape, dtype, begin, record); lat_axis counts from the end (-2: (..., lat, lon))."""
+    shape = list(v['shape'])
+    nd = len(shape)
+    ax = nd + lat_axis
+    if ax < 0 or nd < 2:
+        raise ValueError('variable %s has no latitude axis' % v['name'])
+    item = v['dtype'].itemsize
+    inner = int(np.prod(shape[ax + 1:], dtype=np.int64))          # elements per latitude row
+    nlat = shape[ax]
+    outer = shape[:ax]
+    out = []
+    for idx in np.ndindex(*outer) if outer else [()]:
+        if v['record']:
+            r, rest = idx[0], idx[1:]
+            lin = 0
+            for n, i in zip(shape[1:ax], rest):
+                lin = lin * n + i
+            off = v['begin'] + r * recsize + (lin * nlat + j0) * inner * item
+        else:
+            lin = 0
+            for n, i in zip(outer, idx):
+                lin = lin * n + i
+            off = v['begin'] + (lin * nlat + j0) * inner * item
+        out.append((idx, off, (j1 - j0) * inner * item))
+    return out
+
+
+def read_band(path, name, j0, j1, lat_axis=-2, hdr=None):
+    """Rows [j0, j1) along the latitude axis of variable `name`: array of the variable's shape with that axis cut to
+    j1 - j0, native byte order; one `pread` per (time, level) plane."""
+    import os
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        if hdr is None:
+            hdr = _parse_header(fd, os.fstat(fd).st_size)
+        v = {x['name']: x for x in hdr['vars']}[name]
+        shape = list(v['shape'])
+        ax = len(shape) + lat_axis
+        shape[ax] = j1 - j0
+        out = np.empty(shape, dtype=v['dtype'].newbyteorder('>') if v['dtype'].itemsize > 1 else v['dtype'])
+        for idx, off, nbytes in _band_ranges(v, hdr['recsize'], hdr['numrecs'], j0, j1, lat_axis):
+            if nbytes:
+                _pread_into(fd, out[idx].reshape(-1).view(np.uint8), off)
+    finally:
+        os.close(fd)
+    return out.astype(v['dtype']) if v['dtype'].itemsize > 1 else out
+
+
+class BandedWriter:
+    """An output file several ranks write together: `template` is the Dataset to be written, `banded` the names of the
+    variables every rank holds only a latitude band of (placeholders in the template).  Rank 0 calls `create()` - header,
+    file size, every other variable; after a barrier each rank calls `write_band(name, j0, j1, rows)` for its rows of
+    every banded variable.  The result is byte for byte the file to_netcdf writes from the whole arrays."""
+
+    def __init__(self, template, path, banded, lat_axis=-2):
+        self.ds, self.path, self.banded, self.lat_axis = template, path, tuple(banded), lat_axis
+        hdr, specs, begins, total, recsize, numrecs = _plan(template)
+        self._recsize, self._numrecs = recsize, numrecs
+        self._vars = {}
+        for sp, b in zip(specs, begins):
+            if sp['name'] in self.banded:
+                self._vars[sp['name']] = dict(name=sp['name'], shape=list(sp['data'].shape), dtype=np.dtype(sp['data'].dtype.str[1:]),
+                                              begin=b, record=sp['record'])
+
+    def create(self, threads=None):
+        to_netcdf(self.ds, self.path, threads=threads, skip=self.banded)
+
+    def write_band(self, name, j0, j1, rows):
+        import os
+        v = self._vars[name]
+        rows = np.asarray(rows)
+        want = list(v['shape'])
+        want[len(want) + self.lat_axis] = j1 - j0
+        if list(rows.shape) != want:
+            raise ValueError('band of %s has shape %s, expected %s' % (name, rows.shape, want))
+        big = np.ascontiguousarray(rows.astype(v['dtype'].newbyteorder('>'), copy=False))
+        fd = os.open(self.path, os.O_WRONLY)
+        try:
+            for idx, off, nbytes in _band_ranges(v, self._recsize, self._numrecs, j0, j1, self.lat_axis):
+                mv = memoryview(np.ascontiguousarray(big[idx]).reshape(-1).view(np.uint8))
+                while len(mv):
+                    n = os.pwrite(fd, mv, off)
+                    off += n
+                    mv = mv[n:]
+        finally:
+            os.close(fd)
 
 
 def _to_netcdf_scipy(ds, path):

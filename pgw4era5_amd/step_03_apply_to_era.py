@@ -542,14 +542,26 @@ def pgw_for_era5_arrays(era, deltas, delta_times, plev, target_dt, ignore_top_pr
 _DELTASETS = {}
 
 
-def load_delta_set(ctx, delta_input_dir, dtype):
+class _BandOfRecords:
+    """A record provider cut to latitude rows [j0, j1) (band-wise runs with the record window)."""
+
+    def __init__(self, reader, j0, j1):
+        self.reader, self.j0, self.j1 = reader, j0, j1
+        self.nrec = reader.nrec
+        self.rec_shape = tuple(reader.rec_shape[:-2]) + (j1 - j0, reader.rec_shape[-1])
+
+    def read_record(self, r):
+        return self.reader.read_record(r)[..., self.j0:self.j1, :]
+
+
+def load_delta_set(ctx, delta_input_dir, dtype, band=None):
     """All delta files of a directory -> DeltaSet on the device, cached per process (every ERA5 file of a run uses the
     same deltas).  Like the reference's load_delta (functions.py:195-303) every file brings its own time axis; the four
     model-level variables must share one plev axis (the quad kernel interpolates them together), zg may have its own.
     When all records fit the HBM budget (DeltaSet) the files are read whole; otherwise they are opened record-wise and
     the DeltaSet keeps a window of records per variable on the device."""
     from . import ncio
-    key = (os.path.abspath(delta_input_dir), np.dtype(dtype).str, ctx.device)
+    key = (os.path.abspath(delta_input_dir), np.dtype(dtype).str, ctx.device, band)
     if key in _DELTASETS:
         return _DELTASETS[key]
     readers = {}
@@ -568,15 +580,19 @@ def load_delta_set(ctx, delta_input_dir, dtype):
         if len(plevs[var]) != len(plev) or np.any(plevs[var] != plev):
             raise ValueError('plev axis of %s differs from that of ta (the four model-level deltas are interpolated together)' % var)
     total = sum(r.nrec * int(np.prod(r.rec_shape, dtype=np.int64)) for r in readers.values()) * np.dtype(dtype).itemsize
+    if band is not None:                                                        # (j0, j1): this rank's latitude rows
+        nlat = readers['ta'].rec_shape[-2]
+        total = total * (band[1] - band[0]) // max(nlat, 1)
     forced = os.environ.get('PGW_DELTA_RESIDENT')
     resident = (forced == '1') if forced in ('0', '1') else total <= DeltaSet.budget_bytes(ctx)
     if resident:
         arrays = {}
         for var, r in readers.items():
-            arrays[var] = ncio.open_dataset(r.path)[r.var].values               # whole file, threaded reads
+            a = ncio.open_dataset(r.path)[r.var].values                         # whole file, threaded reads
+            arrays[var] = a if band is None else np.ascontiguousarray(a[..., band[0]:band[1], :])
             r.close()
     else:
-        arrays = readers
+        arrays = readers if band is None else {k: _BandOfRecords(r, band[0], band[1]) for k, r in readers.items()}
     dset = DeltaSet(ctx, arrays, times['ta'], plev, dtype, times_by_var=times, resident=resident)
     dset.plev_zg = plevs['zg']
     _DELTASETS[key] = dset
@@ -881,6 +897,79 @@ def pgw_for_era5(inp_era_file_path, out_era_file_path, delta_input_dir, era_step
         inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt, ignore_top_pressure_error, debug_mode)))))
 
 
+def pgw_for_era5_banded(inp_era_file_path, out_era_file_path, delta_input_dir, era_step_dt, ignore_top_pressure_error,
+                        rank, world, reduce_max, barrier):
+    """ONE ERA5 file over `world` ranks in latitude bands (the latency mode) from file to file:
+    every rank `pread`s its rows of the fields (ncio.read_band: one byte range per (time, level) plane of the classic
+    layout), runs the per-file path on its band with the loop's stopping test made global by `reduce_max`
+    (parallel.band_max_hook: MAX all-reduce of the per-pass figures), and `pwrite`s its rows into the shared output file
+    whose header and remaining variables rank 0 wrote (ncio.BandedWriter).  The file equals the one-rank file byte for
+    byte.  Every rank returns the pass count.  `barrier`: a callable all ranks meet in."""
+    from . import ncio
+    from .parallel import band_rows
+    if S.i_reinterp:
+        raise ValueError('latitude-band sharding of one file needs the multi-pass loop (settings.i_reinterp = 0)')
+    if S.f32_out_dtype not in ('float64', 'float32'):
+        raise ValueError("settings.f32_out_dtype must be 'float64' or 'float32'")
+    vm = S.var_name_map
+    big = dict(T=vm['ta'], QV=vm['hus'], U=vm['ua'], V=vm['va'], PS=vm['ps'], T_SKIN=vm['ts'], T_SO=vm['st'], FR_SEA_ICE=vm['sic'])
+    ctx = default_context()
+    ctx.set_reduce_hook(reduce_max)
+    try:
+        try:
+            if S.i_debug >= 0 and rank == 0:
+                print('Start working on input file {} in {} latitude bands'.format(inp_era_file_path, world))
+            ds = ncio.open_dataset(inp_era_file_path, decode_times=False, skip=tuple(big.values()))      # step_03:60
+            dims4 = (S.TIME_ERA, S.LEV_ERA, S.LAT_ERA, S.LON_ERA)
+            dims3 = (S.TIME_ERA, S.LAT_ERA, S.LON_ERA)
+            for k, name in big.items():
+                want = dims4 if k in ('T', 'QV', 'U', 'V') else ((S.TIME_ERA, S.SOIL_HLEV_ERA, S.LAT_ERA, S.LON_ERA) if k == 'T_SO' else dims3)
+                if ds[name].dims != want:
+                    raise NotImplementedError('band-wise I/O reads %s in the order %s, the file stores %s' % (name, want, ds[name].dims))
+            dtype = np.dtype('float64') if ds[big['T']].dtype.itemsize == 8 else np.dtype('float32')
+            nlat = ds[big['T']].shape[-2]
+            j0, j1 = band_rows(nlat, rank, world)
+            era = {k: np.ascontiguousarray(ncio.read_band(inp_era_file_path, name, j0, j1), dtype=dtype) for k, name in big.items()}
+            for k, name in (('FIS', vm['zgs']), ('FR_LAND', vm['sftlf'])):                               # small: read whole
+                era[k] = np.ascontiguousarray(ds[name].transpose(*dims3).values[..., j0:j1, :], dtype=dtype)
+            coeffs = dict(ak=np.asarray(ds['ak'].values, dtype=np.float64), bk=np.asarray(ds['bk'].values, dtype=np.float64),
+                          soil1=np.asarray(ds[S.SOIL_HLEV_ERA].values, dtype=np.float64))
+            if 'akm' in ds:                                                                              # step_03:68-70
+                coeffs['akm'] = np.asarray(ds['akm'].values, dtype=np.float64)
+                coeffs['bkm'] = np.asarray(ds['bkm'].values, dtype=np.float64)
+            deltas = load_delta_set(ctx, delta_input_dir, dtype, band=(j0, j1))
+            e = _upload_era(ctx, era, dtype)
+        except BaseException:
+            ctx.band_abort()                  # the other bands are on their way into the loop's first reduce: tell them
+            raise
+        out, info = process_file_device(ctx, e, coeffs, deltas, era_step_dt, ignore_top_pressure_error,
+                                        p_ref='local' if S.p_ref_inp is None else S.p_ref_inp)
+        res = {k: out[k].numpy() for k in big}
+        for v in list(e.values()) + [x for x in out.values()]:
+            v.free()
+    finally:
+        ctx.set_reduce_hook(None)
+    narrow = (S.f32_out_dtype == 'float32' and dtype == np.dtype('float32'))
+    F = ncio.Field
+    for k, name in big.items():
+        old = ds[name]
+        dt_out = res[k].dtype
+        if narrow and k in _BIG_OUT:
+            res[k] = res[k].astype(np.float32)                                  # the reference's float64 field rounded once
+            dt_out = np.dtype('float32')
+        ds[name] = F(ncio.placeholder(old.shape, dt_out), old.dims, old.coords, old.attrs)
+    writer = ncio.BandedWriter(ds, out_era_file_path, tuple(big.values()))
+    if rank == 0:
+        writer.create()
+    barrier()
+    for k, name in big.items():
+        writer.write_band(name, j0, j1, res[k])
+    barrier()
+    if S.i_debug >= 1 and rank == 0:
+        print('Done. Saved to file {}.'.format(out_era_file_path))
+    return info['n_iter']
+
+
 pgw_for_era5.stages = (_stage_load, _stage_upload, _stage_compute, _stage_download, _stage_store)
 pgw_for_era5.abort = _ABORT
 pgw_for_era5.reset = reset_after_abort
@@ -902,7 +991,15 @@ def _cli(argv=None):
     p.add_argument('-p', '--n_par', type=int, default=1, help='number of worker ranks = GPUs; files are dealt round-robin')
     p.add_argument('-t', '--ignore_top_pressure_error', action='store_true',
                    help='do not fail if ERA5 reaches higher than the climate deltas')
-    p.add_argument('-D', '--debug_mode', type=str, default=None, help='interpolate_time | interpolate_full (not built)')
+    p.add_argument('-D', '--debug_mode', type=str, default=None,
+                   help='interpolate_time | interpolate_full: the reference dumps the deltas instead of the ERA5 files '
+                        '(step_03_apply_to_era.py:350-361, 387-414) - a validation aid, NOT built here: the run stops with '
+                        'NotImplementedError')
+    p.add_argument('--bands', action='store_true',
+                   help='latency mode: EVERY file is split over all ranks in latitude bands (each rank reads, computes and '
+                        'writes its rows; one MAX all-reduce per loop launch) instead of file i -> rank i mod W.  Needs the '
+                        'ranks of `python -m torch.distributed.run --nproc-per-node W -m pgw4era5_amd.step_03_apply_to_era ...`; '
+                        'settings.i_reinterp = 0.  No counterpart in the reference.')
     args = p.parse_args(argv)
     if args.input_dir is None:
         raise ValueError('Input directory (-i) is required.')
@@ -926,9 +1023,47 @@ def _cli(argv=None):
     step_args = [dict(inp_era_file_path=os.path.join(args.input_dir, S.era5_file_name_base.format(s)),
                       out_era_file_path=os.path.join(args.output_dir, S.era5_file_name_base.format(s)),
                       era_step_dt=s) for s in steps]
+    if args.bands:
+        return _run_banded(fargs, step_args)
     imp = IterMP(njobs=args.n_par, run_async=True)
     imp.run(pgw_for_era5, fargs, step_args)
     return imp.output
+
+
+def _run_banded(fargs, step_args):
+    """`--bands`: all ranks of the torch.distributed.run launch work on ONE file at a time, in latitude bands."""
+    from .parallel import _dist_env, band_max_hook, bind_rank_to_numa
+    rank, world = _dist_env()
+    if fargs.get('debug_mode') is not None:
+        raise NotImplementedError('debug_mode is a validation aid of the reference and not part of the MI355X hot path')
+    if world == 1:
+        return [pgw_for_era5(**dict(fargs, **s)) for s in step_args]
+    import torch                          # before any HIP call of libpgw_hip.so (see _lib.py)
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        backend = os.environ.get('PGW_BANDS_BACKEND') or ('nccl' if torch.cuda.is_available() and torch.cuda.device_count() >= world else 'gloo')
+        if backend == 'nccl':
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group(backend)
+        created = True
+    bind_rank_to_numa()
+    hook = band_max_hook()
+    out, err = [], None
+    try:
+        for s in step_args:
+            out.append(pgw_for_era5_banded(s['inp_era_file_path'], s['out_era_file_path'], fargs['delta_input_dir'], s['era_step_dt'],
+                                           fargs['ignore_top_pressure_error'], rank, world, hook, dist.barrier))
+    except Exception as e:                # noqa: BLE001 - a data error reached every band through the reduce: all ranks are here
+        err = e
+    if created:
+        try:
+            dist.destroy_process_group()
+        except Exception:                 # noqa: BLE001
+            pass
+    if err is not None:
+        raise err
+    return out
 
 
 if __name__ == '__main__':

@@ -581,6 +581,38 @@ def test_a_band_that_fails_fails_all_bands(tmp_path, mode):
             assert msgs[r] == 'ValueError: ', msgs
 
 
+def test_step03_cli_bands_writes_the_one_rank_file_byte_for_byte(files, tmp_path):
+    """`step_03 --bands` under torch.distributed.run with two ranks (gloo here, both on the one GPU): every file is read,
+    computed and written in two latitude bands - each rank `pread`s its rows of the classic NetCDF layout, the loop's
+    stopping test is a MAX all-reduce, each rank `pwrite`s its rows into the output file rank 0 laid out.  The files must
+    be byte for byte what one rank writes (the array-level form: test_one_file_in_two_latitude_bands_is_bit_identical)."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    root, cases = files
+    one = str(tmp_path / 'one')
+    n_one = s3._cli(['-i', str(root / 'era'), '-o', one, '-d', str(root / 'deltas'),
+                     '-f', '2006080200', '-l', '2006080203', '-H', '3', '-p', '1', '-t'])
+    two = str(tmp_path / 'two')
+    log = tmp_path / 'n_iter.txt'
+    script = tmp_path / 'run_bands.py'
+    script.write_text('import sys, os\nsys.path.insert(0, %r)\nimport torch\n'
+                      'from pgw4era5_amd import step_03_apply_to_era as s3\n'
+                      'n = s3._cli(sys.argv[1:])\n'
+                      'open(%r + os.environ["RANK"], "w").write(repr(n))\n' % (ROOT, str(log)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29561', str(script),
+                        '-i', str(root / 'era'), '-o', two, '-d', str(root / 'deltas'),
+                        '-f', '2006080200', '-l', '2006080203', '-H', '3', '-t', '--bands'],
+                       capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_ADDR='127.0.0.1', PGW_BANDS_BACKEND='gloo'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    for rank in ('0', '1'):
+        assert eval(open(str(log) + rank).read()) == n_one                  # every rank knows the (global) pass counts
+    names = sorted(os.listdir(one))
+    assert names == sorted(os.listdir(two)) and len(names) == 2
+    for n in names:
+        assert open(os.path.join(one, n), 'rb').read() == open(os.path.join(two, n), 'rb').read(), n
+
+
 @pytest.mark.parametrize('mode', ['fail_ws', 'fail_cont', 'fail_setup'])
 def test_a_band_that_stops_on_its_own_does_not_leave_the_others_waiting(tmp_path, mode):
     """Latitude-band mode: a band whose pgw_step03_file stops for a reason of its own - the loop's workspace cannot be had

@@ -135,6 +135,56 @@ def test_record_reader_reads_one_record_at_a_time(tmp_path):
         ncio.RecordReader(p, 'nope')
 
 
+@pytest.mark.parametrize('unlimited', [True, False])
+def test_band_wise_netcdf_io_is_byte_identical_to_the_whole_file_writer(tmp_path, unlimited):
+    """ncio.read_band / BandedWriter (one ERA5 file over several ranks in latitude bands): a rank's rows of a (time, level,
+    lat, lon) or (time, lat, lon) variable are one byte range per plane.  Three 'ranks' read their bands of every field
+    from a file and write them into a shared output file whose header and remaining variables rank 0 wrote: byte for byte
+    the file the whole-array writer produces - with an unlimited time dimension (record variables, padded records) and
+    with a fixed one; a field widened to float64 on the way (reference-dtype mode writes float64 T of a float32 file)."""
+    from pgw4era5_amd import ncio
+    from pgw4era5_amd.parallel import band_rows
+    rng = np.random.default_rng(4)
+    nlat, nlon, nlev = 7, 5, 3
+    ds = ncio.Dataset(attrs=dict(title='bands'), record_dim='time' if unlimited else None)
+    F = ncio.Field
+    ds['time'] = F(np.array([12.5, 13.5]), ('time',), attrs=dict(units='hours since 2000-01-01 00:00:00'))
+    ds['lat'] = F(np.linspace(-3, 3, nlat), ('lat',)); ds['lon'] = F(np.arange(nlon) * 1.0, ('lon',))
+    ds['ak'] = F(np.arange(nlev + 1) * 1.0, ('level1',))
+    ds['T'] = F(rng.normal(size=(2, nlev, nlat, nlon)).astype('f4'), ('time', 'level', 'lat', 'lon'), attrs=dict(units='K'))
+    ds['PS'] = F(rng.normal(size=(2, nlat, nlon)).astype('f4'), ('time', 'lat', 'lon'))
+    ds['odd'] = F(rng.integers(-9, 9, size=(2, 3)).astype('i2'), ('time', 'three'))          # 6 bytes per record: padding
+    ds['FIS'] = F(rng.normal(size=(2, nlat, nlon)).astype('f4'), ('time', 'lat', 'lon'))
+    src = str(tmp_path / 'in.nc')
+    ncio.to_netcdf(ds, src)
+    # what the run produces: T widened to float64 and changed, PS changed, FIS passed through
+    newT = ds['T'].values.astype('f8') * 1.5 + 0.25
+    newPS = ds['PS'].values + np.float32(1.0)
+    whole = ncio.open_dataset(src, decode_times=False)
+    whole['T'] = F(newT, whole['T'].dims, whole['T'].coords, whole['T'].attrs)
+    whole['PS'] = F(newPS, whole['PS'].dims, whole['PS'].coords, whole['PS'].attrs)
+    want = str(tmp_path / 'whole.nc')
+    ncio.to_netcdf(whole, want)
+    # band-wise
+    banded = ('T', 'PS')
+    tmpl = ncio.open_dataset(src, decode_times=False, skip=banded)
+    assert ncio.is_placeholder(tmpl['T'].values) and tmpl['T'].shape == (2, nlev, nlat, nlon)
+    tmpl['T'] = F(ncio.placeholder(tmpl['T'].shape, 'f8'), tmpl['T'].dims, tmpl['T'].coords, tmpl['T'].attrs)
+    out = str(tmp_path / 'banded.nc')
+    w = ncio.BandedWriter(tmpl, out, banded)
+    w.create()
+    for rank in (2, 0, 1):                                        # any order once the file exists
+        j0, j1 = band_rows(nlat, rank, 3)
+        t = ncio.read_band(src, 'T', j0, j1)
+        ps = ncio.read_band(src, 'PS', j0, j1)
+        np.testing.assert_array_equal(t, ds['T'].values[:, :, j0:j1]); np.testing.assert_array_equal(ps, ds['PS'].values[:, j0:j1])
+        ncio.BandedWriter(tmpl, out, banded).write_band('T', j0, j1, t.astype('f8') * 1.5 + 0.25)
+        w.write_band('PS', j0, j1, ps + np.float32(1.0))
+    assert open(out, 'rb').read() == open(want, 'rb').read()
+    with pytest.raises(ValueError):
+        w.write_band('PS', 0, 2, np.zeros((2, 3, nlon), 'f4'))
+
+
 def test_native_reader_cdf5(tmp_path):
     """CDF-5 (64-bit data) header layout: counts, dimension ids and sizes are 64-bit, extra integer types.  No
     writer for this format exists in the build environment, so the file is assembled by hand from the format

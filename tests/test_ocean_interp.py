@@ -117,6 +117,50 @@ def test_gauss_interp_properties():
 
 
 @pytest.mark.gpu
+def test_gauss_interp_full_size_config4_ocean_leg():
+    """BASELINE.json configs[3], the tos / siconc leg at production size: 12 months of an 802 x 404 curvilinear ocean grid
+    (NaN over land) onto the 0.25 deg ERA5 grid (721 x 1440) with the defaults of settings.py:127-129 (R = 1000 km,
+    sharpness 4, land above FR_LAND 0.7) - the properties of test_gauss_interp_properties at that size, plus strips of
+    targets along the date line, around the north pole and over a land patch against the oracle (reference
+    functions.py:958-1057: three copies of the planar cloud, Gaussian weights inside the radius)."""
+    from pgw4era5_amd import functions as F, synthetic
+    oc = synthetic.make_ocean_grid_case(nj=404, ni=802, ntime=12, seed=6, land_patches=6)
+    nlat, nlon = 721, 1440
+    lat, lon = _era_grid(nlat, nlon)
+    land = np.zeros((nlat, nlon))
+    land[400:430, 200:260] = 1.0                                               # FR_LAND > 0.7 -> NaN (functions.py:1054-1057)
+    land[500:510, 900:905] = 0.69                                              # below the threshold: stays ocean
+    R, s = 1.0e6, 4.0
+    fields = list(oc['values'])
+    fields[1] = np.where(np.isnan(oc['values'][1]), np.nan, -1.75)            # one constant month
+    got = F.gauss_interp_fields(land, lat, lon, oc['latitude'], oc['longitude'], fields, R, s)
+    assert got.shape == (12, nlat, nlon)
+    ok = ~np.isnan(got[1])
+    np.testing.assert_allclose(got[1][ok], -1.75, rtol=1e-13)                  # constant in -> constant out
+    for m in (0, 5, 11):                                                       # a weighted mean stays inside the data range
+        assert np.nanmin(got[m]) >= np.nanmin(oc['values'][m]) - 1e-12 and np.nanmax(got[m]) <= np.nanmax(oc['values'][m]) + 1e-12
+    assert np.isnan(got[:, 400:430, 200:260]).all() and not np.isnan(got[0][500:510, 900:905]).any()
+    assert np.isnan(got[0][0]).all()                                           # the south pole: farther than R from the ocean grid
+    nan0 = np.isnan(got[0])
+    assert all((np.isnan(got[m]) == nan0).all() for m in range(12))            # one NaN pattern (all months share the land mask)
+    assert 0.85 < (~nan0).mean() < 0.999
+    # strips against the oracle: both sides of the date line, the polar cap, the edge of the land patch
+    checks = [(np.array([60, 200, 333, 520, 650]), np.array([717, 718, 719, 720, 721, 722, 723])),        # lon 179.25 ... 180.75
+              (np.array([708, 712, 716, 719, 720]), np.array([0, 360, 719, 720, 1080, 1439])),            # 87 N ... the pole
+              (np.array([398, 399, 400, 429, 430, 431]), np.array([198, 199, 200, 259, 260, 261]))]
+    for n, (rows, cols) in enumerate(checks):
+        sub = land[np.ix_(rows, cols)]
+        for m in ((0, 7) if n == 0 else (0,)):                                 # (the oracle takes ~10 s per strip and month)
+            want = O.nan_ignoring_interp(sub, lat[rows], lon[cols], oc['latitude'], oc['longitude'], fields[m], R, s)
+            np.testing.assert_allclose(got[m][np.ix_(rows, cols)], want, rtol=1e-10, atol=0, equal_nan=True)
+    # a target that coincides with a source point takes that point's value (vtkGaussianKernel's exact-hit rule)
+    j, i = 150, 333
+    hit = F.gauss_interp_fields(np.zeros((1, 1)), np.array([oc['latitude'][j, i]]), np.array([oc['longitude'][j, i]]),
+                                oc['latitude'], oc['longitude'], [oc['values'][3]], R, s)
+    assert hit[0, 0, 0] == oc['values'][3][j, i]
+
+
+@pytest.mark.gpu
 def test_step02_cli_ocean_variables(tmp_path):
     """`step_02 regridding -v tos`: ocean-grid file with 2-D latitude / longitude in, (time, lat, lon) on the ERA5 grid
     out (reference interp_wrapper, functions.py:1095-1135)."""

@@ -4,7 +4,8 @@
 export TMPDIR=/tmp
 out=gpurun_out/prof_opmix
 mkdir -p $out
-P="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-streams 0 --no-extras $@"
+# OPMIX_PROG: another program than bench.py's timed region, e.g. OPMIX_PROG="python3 tools/reinterp_time.py"
+P="${OPMIX_PROG:-python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap-streams 0 --no-extras} $@"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 --kernel-trace --output-format csv -d $out/f64 -- $P > $out/a.json 2> $out/a.err || echo "f64 pass failed"
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $out/f32 -- $P > $out/b.json 2> $out/b.err || echo "f32 pass failed"
 python3 - <<'PY'
