@@ -159,7 +159,16 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
     return __builtin_fma(a, b, c);
 #else
     double d;
+#ifdef PGW_FMA3_SGPR
+    // A/B knob: the coefficient in a scalar register pair (the one constant-bus operand a VOP3 instruction may take) - no
+    // vector register is held for it, s_mov_b32 literals on the scalar unit materialise it.  Every file-path kernel then
+    // compiles without scratch (k_delta_quad<float, double, REF>: 127 VGPRs / 0 B instead of 128 / 180 B; k_reinterp_pair
+    // with e: 139 / 0 instead of 168 / 116) and runs in the same time (round 3, same box: 2.13 / 2.14, 1.61 / 1.60,
+    // 1.594 / 1.596 ms) - the spilled values are constants of cold paths.  Not the default.
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+#else
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+#endif
     return d;
 #endif
 }

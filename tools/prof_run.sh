@@ -14,7 +14,15 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE
 python3 profiles/summarize.py trace ${tag} $out/trace 2 10 > $out/summ_trace.log 2>&1
 python3 profiles/summarize.py ${tag} $out/trace $out/fetch $out/write $out/sq > $out/summ_pmc.log 2>&1
 python3 profiles/summarize.py trace ${tag} $out/trace 2 10 > $out/summ_trace.log 2>&1
-cp profiles/kernel_stats_${tag}.csv profiles/pmc_summary_${tag}.json $out/ 2>/dev/null
+# the reference's other two modes (p_ref_inp = None, i_reinterp = 1): k_ps_loop_multi<..., LOCAL> and k_reinterp_pair
+M="python3 tools/modes_run.py $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/mtrace -- $M > $out/modes_trace.json 2> $out/mtrace.err || echo "modes trace failed"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/mfetch -- $M > $out/modes_fetch.json 2> $out/mfetch.err || echo "modes fetch failed"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/mwrite -- $M > $out/modes_write.json 2> $out/mwrite.err || echo "modes write failed"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/msq -- $M > $out/modes_sq.json 2> $out/msq.err || echo "modes sq failed"
+python3 profiles/summarize.py ${tag}_modes $out/mtrace $out/mfetch $out/mwrite $out/msq > $out/summ_modes_pmc.log 2>&1
+python3 profiles/summarize.py trace ${tag}_modes $out/mtrace 2 4 > $out/summ_modes_trace.log 2>&1
+cp profiles/kernel_stats_${tag}.csv profiles/pmc_summary_${tag}.json profiles/kernel_stats_${tag}_modes.csv profiles/pmc_summary_${tag}_modes.json $out/ 2>/dev/null
 # keep the merged-back directory small: per-dispatch counter tables are large
 find $out -name "*counter_collection.csv" -size +3M -delete
 find $out -name "*kernel_trace.csv" -size +3M -delete
