@@ -870,7 +870,8 @@ def mode_leg(ctx, era, coeffs, deltas, case, a, which, files=4, warmup=2):
     while n_pure < N and (0.5 * (bk[n_pure + 1] - bk[n_pure]) + bk[n_pure]) == 0.0:
         n_pure += 1
     touched = sum(i.get('levels_touched', 0) for i in infos)
-    kinfo = dict(so=s, levels_per_launch=touched / max(passes, 1), qv_done_levels=n_pure if ctx.get_option('quad') != 0 else 0,
+    so = 8 if s3.ref_dtype_mode(era['T'].dtype) else s          # float32 files in reference-dtype mode: float64 level arrays out
+    kinfo = dict(so=so, levels_per_launch=touched / max(passes, 1), qv_done_levels=n_pure if ctx.get_option('quad') != 0 else 0,
                  passes_per_launch=(sum(i.get('passes_launched', 0) for i in infos) / prof['ps_loop_multi'][0])
                  if prof['ps_loop_multi'][0] else 1.0)
     kern = {}
@@ -880,7 +881,10 @@ def mode_leg(ctx, era, coeffs, deltas, case, a, which, files=4, warmup=2):
         # i_reinterp: the pair kernel (k_reinterp_pair: two ERA fields + two deltas onto the current levels) runs under the
         # vert_interp_delta id: 2 fields in, 2 out, 2 records x S x 2 variables, ~6 2-D fields
         if which == 'reinterp' and k == 'vert_interp_delta':
-            b = (4 * N + 4 * S + 6) * ncol * s
+            # ta + hur inside the loop (n_iter launches per file): T (s) and RELHUM (so) in, ta_pgw, hur_pgw and e (so) out;
+            # ua + va once: U, V (s) in, two fields (so) out; 2 records x S x 2 variables and ~6 2-D fields each
+            n_th, n_w = sum(i['n_iter'] for i in infos), len(infos)
+            b = (n_th * (N * (s + so) + 3 * N * so) + n_w * (2 * N * s + 2 * N * so)) / (n_th + n_w) * ncol + (4 * S + 6) * ncol * s
         elif k in ('adjust_ps_step', 'ps_loop_multi', 'phi_ref_hybrid') and not touched:
             b = 0                                # levels read per pass not reported by this path: no byte figure
         else:

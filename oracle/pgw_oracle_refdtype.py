@@ -26,11 +26,16 @@ WITHOUT any up-front cast, so that on float32 inputs it computes what the refere
     delta's dtype and the rest in float64.
 
 Promotion rules: the reference pins numpy 1.23.5 (environment.yml:133, value-based casting); this
-container has numpy 2.2 (NEP 50).  Both give float32 for `python scalar (op) float32 array`, and
-that is the only mixed case on this path, provided constants enter as python floats - they do
-below, as they do in the reference (constants.py, settings.py).  numpy float64 SCALARS meeting
-float32 arrays would differ between the two versions; the path has none (np.log(p_ref) only meets
-float64 arrays).
+container has numpy 2.2 (NEP 50).  Both give float32 for `python scalar (op) float32 array`, the
+common mixed case on this path - constants enter as python floats below, as they do in the
+reference (constants.py, settings.py).  They DIFFER for a 0-d integer ARRAY meeting a float32
+array: `xr.where(cond, 1, alpha)` (functions.py:97-100) goes through
+`as_shared_dtype([asarray(1), alpha])`; under 1.23.5's value-based casting the 0-d int64 array does
+not promote a float32 `alpha` (result float32), under NEP 50 it would (float64).  The restatement
+below therefore writes `np.where(cond, 1, alpha).astype(ta.dtype)` - it FORCES the reference's
+(1.23.5) result instead of relying on this container's numpy.  numpy float64 SCALARS meeting
+float32 arrays would differ between the two versions as well; the path has none (np.log(p_ref)
+only meets float64 arrays).
 
 What cannot be pinned bit for bit: np.exp on float32 arrays (SIMD implementation of the numpy
 build) - the reference's own last-bit noise in RELHUM of the ERA state.
@@ -94,8 +99,10 @@ def saturation_vapor_pressure_water_or_ice(pa, ta, water=True):
 
 
 def saturation_vapor_pressure_water_and_ice(pa, ta):
-    """functions.py:91-105: alpha = full_like(ta) -> the whole chain stays in ta's dtype
-    (xr.where(cond, 1, alpha): python int with a float32 array -> float32)."""
+    """functions.py:91-105: alpha = full_like(ta) -> the whole chain stays in ta's dtype.  xr.where(cond, 1, alpha) turns
+    the 1 into a 0-d integer array; under the reference's numpy 1.23.5 (value-based casting) that does not promote a float32
+    alpha, under this container's numpy 2.2 it would: the .astype(ta.dtype) below forces the reference's result (module
+    docstring)."""
     T0, Ti = 273.16, 250.16
     ta = _a(ta)
     alpha = np.full_like(ta, np.nan)
