@@ -842,7 +842,7 @@ def test_reinterp_mode_vs_oracle(mode, p_ref):
         # ps_pgw may sit one float32 ulp beside the oracle's (the device logarithm against numpy's); the
         # re-interpolated fields carry that 6e-8 relative pressure shift times their vertical gradient: white noise in the
         # synthetic winds (sigma 10 m/s per level), a lapse rate in T
-        np.testing.assert_allclose(got['T'], want['T'], rtol=2e-8, err_msg='T')
+        np.testing.assert_allclose(got['T'], want['T'], rtol=6e-8, err_msg='T')
         for k in ('U', 'V'):
             np.testing.assert_allclose(got[k], want[k], rtol=0, atol=2e-5, err_msg=k)
     else:
