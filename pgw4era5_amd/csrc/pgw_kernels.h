@@ -559,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
 // resumes from the previous hit while targets ascend (all earlier sources are < the previous target <= x, so
 // they cannot match) and restarts from 0 otherwise -> identical selection, O(N+S).
 // =====================================================================================
-// Nothing is staged.  A column keeps a window of its source profile in registers - levels j-2, j-1, j (the scan
+// No field is staged (only the 2 KB table of the logarithm).  A column keeps a window of its source profile in registers - levels j-2, j-1, j (the scan
 // position) and j+1, with the loads of level j+2 in flight - and moves it forward when a target passes level j, so
 // every source element is read exactly once, one scan step ahead of its use, and the kernel runs at full occupancy
 // (a [level][thread] LDS tile of the source columns caps the CU at 8 waves at S = 19: 0.91 vs 0.54 ms).
@@ -567,11 +567,18 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_ps_hus(Levels lv, int ntime,
 #ifndef PGW_INTERP_MINB
 #define PGW_INTERP_MINB 1
 #endif
+#define PGW_LOGT(x) pgw_log_tab((x), s_logt)
 template <typename T, int MODE>
 __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(int ntime, int S, int N, long long ncol,
                                                               const T *__restrict__ var, const T *__restrict__ srcP,
                                                               const T *__restrict__ trgP, T *__restrict__ out,
                                                               int logp_in, DevStatus *st) {
+    // np.log of both pressure fields (:470-471) through the table-driven logarithm of the level loops (pgw_log_tab: ~27
+    // instead of ~40 instructions, same <= 1 ulp; S + N = 156 logarithms per column made this kernel issue-bound: 0.86 busy).
+    // Source and target logarithms come from the one implementation, so the exact-hit rule (:540) is unaffected.
+    __shared__ double s_logt[2 * LOG_TABLE_N];
+    stage_log_table(s_logt, BLOCK);
+    __syncthreads();
     long long flat = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (flat >= (long long)ntime * ncol) return;
     long long t = flat / ncol, c = flat - t * ncol;
@@ -579,13 +586,13 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
     const T *pp = srcP + t * S * ncol + c;
     const T *pt = trgP + t * N * ncol + c;
     T *po = out + t * N * ncol + c;
-    const double s_first = logp_in ? (double)pp[0] : pgw_log((double)pp[0]);                         // :470
+    const double s_first = logp_in ? (double)pp[0] : PGW_LOGT((double)pp[0]);                         // :470
     {
         double s_last = (double)pp[(long long)(S - 1) * ncol];
-        if (!logp_in) s_last = pgw_log(s_last);
+        if (!logp_in) s_last = PGW_LOGT(s_last);
         if (s_last < s_first) { report(st, 10, flat); }              // :500-501
         double x_first = (double)pt[0], x_last = (double)pt[(long long)(N - 1) * ncol];
-        if (!logp_in) { x_first = pgw_log(x_first); x_last = pgw_log(x_last); }
+        if (!logp_in) { x_first = PGW_LOGT(x_first); x_last = PGW_LOGT(x_last); }
         if (x_last < x_first) { report(st, 11, flat); }              // :502-503
     }
     // source window
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
         j = 0;
         xj = s_first; yj = (double)pv[0];
         xn = (double)pp[ncol]; yn = (double)pv[ncol];                // S >= 2
-        if (!logp_in) xn = pgw_log(xn);
+        if (!logp_in) xn = PGW_LOGT(xn);
         const long long o = (long long)(2 < S ? 2 : S - 1) * ncol;
         rx = (double)SIG_LD(pp + o); ry = (double)SIG_LD(pv + o);
     };
@@ -618,14 +625,14 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
             const int l = l0 + u;
             if (l < N) {
                 double x = cx[u];
-                if (!logp_in) x = pgw_log(x);                            // :471
+                if (!logp_in) x = PGW_LOGT(x);                            // :471
                 if (__builtin_expect(!(x >= xprev), 0)) {                // restart (descending or NaN target)
                     x = no_speculate(x);
                     reset();
                 }
                 while (j < S && !(xj == x || xj > x)) {                  // first s with src[s] == x or src[s] > x
                     xmm = xm; ymm = ym; xm = xj; ym = yj; xj = xn; yj = yn;
-                    xn = logp_in ? rx : pgw_log(rx); yn = ry;
+                    xn = logp_in ? rx : PGW_LOGT(rx); yn = ry;
                     ++j;
                     const long long o = (long long)(j + 2 < S ? j + 2 : S - 1) * ncol;
                     rx = (double)SIG_LD(pp + o); ry = (double)SIG_LD(pv + o);
@@ -658,6 +665,7 @@ __global__ __launch_bounds__(BLOCK, PGW_INTERP_MINB) void k_interp_logp_stream(i
     }
 }
 
+#undef PGW_LOGT
 // =====================================================================================
 // a7  time lerp of load_delta                                   functions.py:288-292
 // =====================================================================================
