@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
                     st_off_nt(rv.out[0], o, r0);
                     st_off_nt(rv.out[1], o, r1);
                     if (EVAP) st_off(rv.evap, o, (TO)rh_to_e((double)r1, (double)r0));
-                    xprev = (x == x) ? x : __builtin_inf();
+                    xprev = x;           // a NaN target leaves NaN here: the next level's `!(x >= xprev)` restarts the scans, as +inf did
                 }
             }
         }
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
                     else x = pgw_log_tab(pa, s_logt);
                     if (!(x >= xprev)) { j1 = 0; j2 = 0; }
                     while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
-                    xprev = (x == x) ? x : __builtin_inf();
+                    xprev = x;           // a NaN target leaves NaN here: the next level's `!(x >= xprev)` restarts the scans, as +inf did
                     // ua, va on the plain plev axis
                     double dc, dd;
                     int p1, p2;                                                    // its bracket
