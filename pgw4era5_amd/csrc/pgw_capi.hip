@@ -1607,7 +1607,7 @@ static int step03_file(pgw_ctx *ctx, pgw_file_args *a) {
         if ((rc = status_reset(ctx))) return rc;
         if (ctx->opt[PGW_OPT_QUAD]) {
             // ---- all four variables in one kernel (production)
-            const size_t qlds = (size_t)3 * N * sizeof(double) + (size_t)N * sizeof(int);
+            const size_t qlds = (size_t)3 * N * sizeof(double);
             qv_done = ctx->opt[PGW_OPT_FULL_COLUMN] ? 0 : ctx->n_pure;     // full-column passes read e at every level
             {
                 Prof pr(ctx, PGW_K_QUAD_DELTA);

@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
     // (instead of e, which only the levels below p_ref and k_finalize_ps_hus need) and the finalize kernel skips them.
     // n_pure_lv: number of leading pure-pressure levels (n_pure is 0 when the QV shortcut is off); their pressure akm[l]
     // is the same in every column, so ln(akm[l]) is taken once per block instead of once per column and level
-    extern __shared__ double lds_quad[];            // akm[N] | bkm[N] | ln(akm)[N] (first n_pure_lv entries) | int scan position[N] (same)
+    extern __shared__ double lds_quad[];            // akm[N] | bkm[N] | ln(akm)[N] (first n_pure_lv entries)
     __shared__ double s_mint[TPB / 64], s_mins[TPB / 64];
     __shared__ int s_nan[TPB / 64];
     __shared__ double s_lnp[MAX_PLEV];
@@ -1547,20 +1547,6 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
     __syncthreads();
     for (int i = threadIdx.x; i < n_pure_lv; i += TPB) s_lnpa[i] = pgw_log_tab(s_akm[i], s_logt);
     __syncthreads();
-    // ... and so does the plain scan's position there: the first source index with ln(plev) == x or > x (functions.py:527-548)
-    // is the same in every column with a finite surface pressure, so it is looked up once per block and level instead of
-    // scanned for per column (the restart test, the scan loop and its LDS reads on 44 of 137 levels: 1.51 -> 1.47 ms).  Only
-    // while the pure levels' pressures ascend (n_scan: the leading levels for which that holds); other levels and columns scan.
-    int *s_pj = reinterpret_cast<int *>(lds_quad + 3 * lv.nlev);
-    for (int i = threadIdx.x; i < n_pure_lv; i += TPB) {
-        const double x = s_lnpa[i];
-        int j = 0;
-        while (j < S) { const double xs = s_lnp[j]; if (xs == x || xs > x) break; ++j; }
-        s_pj[i] = (i == 0 || s_lnpa[i] >= s_lnpa[i - 1]) ? j : -1;        // -1: not ascending here, every later level scans
-    }
-    __syncthreads();
-    int n_scan = 0;
-    while (n_scan < n_pure_lv && s_pj[n_scan] >= 0) ++n_scan;
     long long flat = (long long)blockIdx.x * TPB + threadIdx.x;
     double min_t = __builtin_inf(), min_s = __builtin_inf();
     int nanflag = 0;
@@ -1716,11 +1702,8 @@ __global__ __launch_bounds__(TPB, (sizeof(T) == 4 ? QUAD_MINW_F32 : QUAD_MINW)) 
                     double x;                                                      // functions.py:471
                     if (l < n_pure_lv) x = ps_finite ? s_lnpa[l] : pa;             // pa == akm[l]; NaN for a non-finite ps
                     else x = pgw_log_tab(pa, s_logt);
-                    if (l < n_scan && ps_finite) j2 = s_pj[l];                    // pure-pressure level: the block's lookup
-                    else {
-                        if (!(x >= xprev)) { j1 = 0; j2 = 0; }
-                        while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
-                    }
+                    if (!(x >= xprev)) { j1 = 0; j2 = 0; }
+                    while (j2 < S) { double xs = s_lnp[j2]; if (xs == x || xs > x) break; ++j2; }
                     xprev = x;           // a NaN target leaves NaN here: the next level's `!(x >= xprev)` restarts the scans, as +inf did
                     // ua, va on the plain plev axis
                     double dc, dd;
