@@ -221,7 +221,7 @@ def cli_leg_all_ranks(a, rank, world, dist, barrier, files_per_rank=3):
     first = dt.datetime(2006, 8, 2, 0)
     last = first + dt.timedelta(hours=nfiles - 1)
     old_debug, old_out = S.i_debug, S.f32_out_dtype
-    S.i_debug = 0
+    S.i_debug = -1
     try:
         for mode, why_not in plan['modes']:
             key = 'float64_out' if mode == 'float64' else 'float32_out'
@@ -236,7 +236,9 @@ def cli_leg_all_ranks(a, rank, world, dist, barrier, files_per_rank=3):
             barrier()
             t0 = time.time()
             try:
-                n_iter = s3._cli(argv)
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):     # the command line's progress lines must not reach the stdout
+                    n_iter = s3._cli(argv)                       # that carries this program's ONE result line
             except Exception as e:      # noqa: BLE001
                 err, n_iter = '%s: %s' % (type(e).__name__, e), None
             barrier()
