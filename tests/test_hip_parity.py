@@ -858,6 +858,27 @@ def test_reinterp_mode_vs_oracle(mode, p_ref):
     assert np.abs(base['T'].astype(np.float64) - got['T']).max() > 1e-6
 
 
+@pytest.mark.parametrize('p_ref', [None, 'local'])
+def test_reinterp_reference_dtype_mode_with_64_bit_offsets_is_bit_identical(p_ref):
+    """The 64-bit byte-offset instantiations of k_reinterp_pair's mixed-type forms (float32 ERA field, float64 RELHUM and
+    outputs: the second field's and the outputs' offsets are the first field's scaled by the element-size ratio) - the
+    path arrays of 4 GiB and more take - give the bits of the 32-bit ones."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    c = _case(6, 9, 21, seed=35, dtype=np.float32)
+    args = (c['era'], c['deltas'], c['delta_times'], c['plev'], c['target_dt'], True)
+    a = s3.pgw_for_era5_arrays(*args, i_reinterp=True, p_ref=p_ref, ref_dtype=True)
+    old = ctx.set_option('force_off64', 1)
+    try:
+        b = s3.pgw_for_era5_arrays(*args, i_reinterp=True, p_ref=p_ref, ref_dtype=True)
+    finally:
+        ctx.set_option('force_off64', old)
+    assert a['n_iter'] == b['n_iter'] and a['max_err'] == b['max_err']
+    for k in ('PS', 'T', 'QV', 'U', 'V'):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 @pytest.mark.parametrize('dtype', [np.float64, np.float32])
 def test_reinterp_one_call_path_is_the_host_composed_path_bit_for_bit(dtype):
     """pgw_step03_file with i_reinterp (one C call per file) against the same path composed on the host from the
