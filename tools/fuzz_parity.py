@@ -116,7 +116,7 @@ def one(rng, i, run=True, debug=False):
         elif dtype == np.float32:
             got = s3.pgw_for_era5_arrays(*args)
             want = R.pgw_for_era5_arrays(*args)
-            tol = dict(PS=2.5e-7, T=1e-9, QV=6e-7)
+            tol = dict(PS=3.2e-7, T=1e-9, QV=6e-7)      # PS: up to 4 float32 ulp (device log vs numpy)
         else:
             got = s3.pgw_for_era5_arrays(*args)
             want = O.pgw_for_era5_arrays(*args)
