@@ -1072,8 +1072,8 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
     __shared__ int s_nan[BLOCK / 64];
     __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
     __shared__ double s_logt[2 * LOG_TABLE_N];
-    __shared__ TE0 s_ring0[RING][BLOCK];
-    __shared__ TE1 s_ring1[RING][BLOCK];
+    __shared__ TE0 s_ring0[RING + 1][BLOCK];         // slot RING: see era_at
+    __shared__ TE1 s_ring1[RING + 1][BLOCK];
     const int S = pt.n, N = lv.nlev;
     double *s_akm = lds_rp, *s_bkm = lds_rp + N;
     stage_log_table(s_logt, BLOCK);
@@ -1166,9 +1166,20 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
         // ---- the ring: at target level l it holds the ERA levels [l - 3, l + 5)
         const int tid = threadIdx.x;
         int ring_lo = 0;                                               // l - 3 (may be negative)
+        // A level the ring does not hold (the two surface pressures more than 3-4 levels apart, or a restart) is fetched from
+        // global memory INTO the thread's spare ring slot and read from there like any other: the window's values then never
+        // depend on a vector-memory load outside this branch.  (Returned in registers, the compiler had to put
+        // `s_waitcnt vmcnt(0)` at the head of the window loop - where the two paths merge - which drained the eight prefetched
+        // rows and every store in flight at almost every level: 0.52 of the wave time was spent in s_waitcnt.)
         auto era_at = [&](int lev, double &u, double &v) {
-            if ((unsigned)(lev - ring_lo) < (unsigned)RING) { u = (double)s_ring0[lev & (RING - 1)][tid]; v = (double)s_ring1[lev & (RING - 1)][tid]; }
-            else { const O o = lev_off(lev); u = (double)ld_off(pf0, o); v = (double)ld_off(pf1, off1(o)); }
+            int slot = lev & (RING - 1);
+            if (__builtin_expect(!((unsigned)(lev - ring_lo) < (unsigned)RING), 0)) {
+                const O o = lev_off(lev);
+                s_ring0[RING][tid] = ld_off(pf0, o);
+                s_ring1[RING][tid] = ld_off(pf1, off1(o));
+                slot = RING;
+            }
+            u = (double)s_ring0[slot][tid]; v = (double)s_ring1[slot][tid];
         };
         TE0 na[RING_LEAD];                                              // rows in flight: levels l + 4 .. l + 7 at the top of level l
         TE1 nb[RING_LEAD];
