@@ -1054,6 +1054,9 @@ constexpr int RING = 8, RING_LEAD = 4;
 #ifndef RP_MINW
 #define RP_MINW 4
 #endif
+#ifndef RP_SPARE_ALL
+#define RP_SPARE_ALL 0
+#endif
 // O: byte-offset type of ld_off / st_off (32-bit when every array is smaller than 4 GiB)
 // EVAP (ta + hur inside the loop): also writes e = hur_pgw / 100 * e_sat(ta_pgw) (functions.py:123) of the STORED values,
 // the iterate-independent half of relative_to_specific_humidity that k_adjust_ps_step reads - the bits of a separate
@@ -1072,8 +1075,11 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
     __shared__ int s_nan[BLOCK / 64];
     __shared__ double s_p[MAX_PLEV], s_lnp[MAX_PLEV];
     __shared__ double s_logt[2 * LOG_TABLE_N];
-    __shared__ TE0 s_ring0[RING + 1][BLOCK];         // slot RING: see era_at
-    __shared__ TE1 s_ring1[RING + 1][BLOCK];
+    // slot RING: see era_at.  Not for float64 fields without `e` (RP_SPARE): that instantiation runs 4 blocks per CU, and the
+    // ninth slot (2 x 2 KB) would cost it one of them.
+    constexpr bool SPARE = RP_SPARE_ALL || EVAP || (sizeof(TE0) + sizeof(TE1) < 16);
+    __shared__ TE0 s_ring0[RING + (SPARE ? 1 : 0)][BLOCK];
+    __shared__ TE1 s_ring1[RING + (SPARE ? 1 : 0)][BLOCK];
     const int S = pt.n, N = lv.nlev;
     double *s_akm = lds_rp, *s_bkm = lds_rp + N;
     stage_log_table(s_logt, BLOCK);
@@ -1172,14 +1178,19 @@ __global__ __launch_bounds__(BLOCK, (EVAP ? RP_MINW_EVAP : RP_MINW)) void k_rein
         // `s_waitcnt vmcnt(0)` at the head of the window loop - where the two paths merge - which drained the eight prefetched
         // rows and every store in flight at almost every level: 0.52 of the wave time was spent in s_waitcnt.)
         auto era_at = [&](int lev, double &u, double &v) {
-            int slot = lev & (RING - 1);
-            if (__builtin_expect(!((unsigned)(lev - ring_lo) < (unsigned)RING), 0)) {
-                const O o = lev_off(lev);
-                s_ring0[RING][tid] = ld_off(pf0, o);
-                s_ring1[RING][tid] = ld_off(pf1, off1(o));
-                slot = RING;
+            if constexpr (SPARE) {
+                int slot = lev & (RING - 1);
+                if (__builtin_expect(!((unsigned)(lev - ring_lo) < (unsigned)RING), 0)) {
+                    const O o = lev_off(lev);
+                    s_ring0[RING][tid] = ld_off(pf0, o);
+                    s_ring1[RING][tid] = ld_off(pf1, off1(o));
+                    slot = RING;
+                }
+                u = (double)s_ring0[slot][tid]; v = (double)s_ring1[slot][tid];
+            } else {
+                if ((unsigned)(lev - ring_lo) < (unsigned)RING) { u = (double)s_ring0[lev & (RING - 1)][tid]; v = (double)s_ring1[lev & (RING - 1)][tid]; }
+                else { const O o = lev_off(lev); u = (double)ld_off(pf0, o); v = (double)ld_off(pf1, off1(o)); }
             }
-            u = (double)s_ring0[slot][tid]; v = (double)s_ring1[slot][tid];
         };
         TE0 na[RING_LEAD];                                              // rows in flight: levels l + 4 .. l + 7 at the top of level l
         TE1 nb[RING_LEAD];
