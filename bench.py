@@ -350,6 +350,10 @@ def roofline_object(dom, kern, a):
     return roof
 
 
+def dom_streams_ok(era, out):
+    return all(k in era for k in ('T', 'QV', 'U', 'V')) and all(k in out for k in ('T', 'QV', 'U', 'V'))
+
+
 def kernel_table(prof, N, S, ncol, s, kinfo):
     """per-kernel launches / average ms / algorithmic GB / GB/s from the context's HIP-event profile"""
     kern = {}
@@ -477,20 +481,46 @@ def main(argv=None):
                 torch.cuda.synchronize()
 
     infos = []
+    smi = None
+    if rank == 0 and not os.environ.get('PGW_BENCH_NOSMI'):
+        # the card's own telemetry over the run (gfx clock, socket power against its cap, temperatures): the file path drives
+        # an MI355X to its power cap, and the clock the firmware then allows is what differs between boxes
+        try:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'smi'))
+            from sampler import Sampler
+            smi = Sampler(device=local).start()
+        except Exception:                           # noqa: BLE001 - telemetry is optional
+            smi = None
     if not os.environ.get('PGW_BENCH_NOPROF'):      # A/B knob: cost of the per-launch HIP events
         ctx.profile(True)                           # on during warm-up too, so the event pool is populated
     for i in range(a.warmup):
         _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[i], True, out=out, ref_dtype=ref)
     ctx.profile_reset()
     barrier()
+    tm0 = time.monotonic()
     t0 = time.perf_counter()
     for i in range(a.steps):
         _, info = s3.process_file_device(ctx, era, coeffs, deltas, stamps[a.warmup + i], True, out=out, ref_dtype=ref)
         infos.append(info)
     barrier()
     elapsed = time.perf_counter() - t0
+    tm1 = time.monotonic()
     prof = {k: ctx.profile_get(k) for k in FILE_KERNELS}
     solo = (rank == 0 and world == 1)
+    bare = None
+    if rank == 0 and dom_streams_ok(era, out):
+        # the quad kernel's access pattern with no arithmetic (4 read + 4 write streams, Context.placement_probe) on the very
+        # arrays of this run: what this box gives the pattern WHERE these arrays lie (5.0-6.2 TB/s between allocations, DESIGN.md
+        # section 4).  Overwrites the outputs of the last file; every later leg writes them anew.
+        try:
+            ctx.profile(False)
+            g = ctx.placement_probe([era[k] for k in ('T', 'QV', 'U', 'V')], [out[k] for k in ('T', 'QV', 'U', 'V')], reps=5)
+            bare = {'GBps': round(g, 1), 'frac_of_peak': round(g / HBM_PEAK_GBS, 4),
+                    'what': 'k_placement_probe: 4 read + 4 write streams over the ERA inputs and the outputs of this run, '
+                            'one thread per column, two levels per step, streaming loads / stores, no arithmetic'}
+            ctx.profile(not os.environ.get('PGW_BENCH_NOPROF'))
+        except Exception as e:                      # noqa: BLE001 - a side measurement
+            bare = {'error': '%s: %s' % (type(e).__name__, e)}
     micro = microbench(ctx, era, coeffs, a, np) if solo else {}       # N = 1 only: keeps multi-rank runs short
     for k, v in micro.items():
         # beside the HIP-event figure of this run: the fraction from the committed rocprofv3 trace of the same command.
@@ -551,6 +581,10 @@ def main(argv=None):
             return 0
         dom = max(cand, key=lambda k: kern[k]['total_ms'])
         roof = roofline_object(dom, kern, a)
+        if bare is not None:
+            roof['bare_pattern_same_arrays'] = bare
+            if bare.get('GBps') and kern[dom]['GBps']:
+                roof['frac_of_bare_pattern'] = round(kern[dom]['GBps'] / bare['GBps'], 4)
         files = a.steps * world
         res = {
             'metric': 'ERA5 files/hour (0.25deg L137), step_03 hot path, inputs resident in HBM',
@@ -596,6 +630,9 @@ def main(argv=None):
             # float32 files in reference-dtype mode - what real ERA5 files run by default - beside the float64 object
             res['roofline_f32ref'] = dict(f32s['reference']['roofline'], ms_per_file=f32s['reference']['ms_per_file'],
                                           iterations=f32s['reference']['iterations'])
+        if smi is not None:
+            smi.stop()
+            res['device_state'] = smi.summary(tm0, tm1)
         if cpu is not None:
             res['cpu_baseline'] = cpu
         assert res['n_gpus'] == a.gpus == ranks_seen, (res['n_gpus'], a.gpus, ranks_seen)

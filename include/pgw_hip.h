@@ -434,6 +434,19 @@ int pgw_gauss_interp(pgw_ctx *ctx, long long ntarg, const double *tx, const doub
 int pgw_planar_metres(pgw_ctx *ctx, long long n, const double *lat, const double *lon, double *lat_m, double *lon_m,
                       double *lon_off);
 
+/* Placement of the level arrays in HBM (no counterpart in the reference: numpy arrays live wherever malloc put them).
+ * On an MI355X the rate a column kernel gets depends on WHERE hipMalloc put its arrays relative to each other: an array
+ * written while an array of the same stretch of physical memory is read runs at 5.0-5.4 TB/s, arrays of different stretches
+ * at 5.7-6.2.  pgw_placement_probe measures it for a given set: the column kernels' access pattern
+ * with no arithmetic over n_src (0..4) read streams and n_dst (0..4) write streams of rows x ncol float64 each, `reps`
+ * timed launches after one warm-up, *gbps = bytes moved / time.  The dst arrays are OVERWRITTEN.  Synchronous.
+ * pgw_ws_adopt hands the library a pgw_malloc'ed buffer as its workspace `slot` (0 = the vapour-pressure field of the
+ * file path, one ERA5 level field of float64) so that the host layer can choose that array's place too; the library owns
+ * and frees it from then on; (NULL, 0) releases the slot. */
+int pgw_placement_probe(pgw_ctx *ctx, int n_src, const void *const *src, int n_dst, void *const *dst, long long rows,
+                        long long ncol, int reps, double *gbps);
+int pgw_ws_adopt(pgw_ctx *ctx, int slot, void *dptr, size_t bytes);
+
 /* Byte-order conversion on the device: dst[i] = byte-reversed src[i] for n elements of 4 or 8 bytes (in place
  * allowed).  NetCDF classic files are big-endian (the reference reads / writes them through xarray,
  * step_03_apply_to_era.py:60, 378, which converts on the host); with this entry the raw file bytes are uploaded

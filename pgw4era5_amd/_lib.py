@@ -131,6 +131,8 @@ SIGNATURES['pgw_test_exp'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_test_shared_div'] = (_i, [_vp, _ll, _vp, _vp, _vp])
 SIGNATURES['pgw_test_rh_f32'] = (_i, [_vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES['pgw_byteswap'] = (_i, [_vp, _i, _ll, _vp, _vp])
+SIGNATURES['pgw_placement_probe'] = (_i, [_vp, _i, C.POINTER(C.c_void_p), _i, C.POINTER(C.c_void_p), _ll, _ll, _i, C.POINTER(C.c_double)])
+SIGNATURES['pgw_ws_adopt'] = (_i, [_vp, _i, _vp, C.c_size_t])
 SIGNATURES['pgw_narrow_f64_f32'] = (_i, [_vp, _ll, _vp, _vp, _i])
 SIGNATURES['pgw_harmonic_smooth'] = (_i, [_vp, _i, _i, _ll, _dp, _dp, _vp, _vp])
 SIGNATURES['pgw_gauss_interp'] = (_i, [_vp, _ll, _vp, _vp, _i, _i, _d, _d, _d, _vp, _ll, _vp, _vp, _vp, _i, _d, _d, _vp])

@@ -1767,6 +1767,49 @@ extern "C" int pgw_planar_metres(pgw_ctx *ctx, long long n, const double *lat, c
     return PGW_OK;
 }
 
+extern "C" int pgw_placement_probe(pgw_ctx *ctx, int n_src, const void *const *src, int n_dst, void *const *dst, long long rows,
+                                   long long ncol, int reps, double *gbps) {
+    NEED(ctx, n_src >= 0 && n_src <= 4 && n_dst >= 0 && n_dst <= 4 && n_src + n_dst > 0, "1 to 4 + 4 streams");
+    NEED(ctx, rows > 0 && ncol > 0 && reps > 0 && gbps, "bad argument");
+    ProbeStreams s;
+    s.ns = n_src; s.nd = n_dst;
+    for (int i = 0; i < 4; ++i) {
+        s.src[i] = i < n_src ? (const double *)src[i] : nullptr;
+        s.dst[i] = i < n_dst ? (double *)dst[i] : nullptr;
+        NEED(ctx, (i >= n_src || (s.src[i] && ((uintptr_t)s.src[i] % 8) == 0)) && (i >= n_dst || (s.dst[i] && ((uintptr_t)s.dst[i] % 8) == 0)),
+             "stream pointers must be non-null and 8-byte aligned");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0 = nullptr, e1 = nullptr;             // its own pair: pgw_timer_start / _stop of the caller stay untouched
+    HIPCHK(ctx, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return fail(ctx, PGW_ERR_HIP, "hipEventCreate failed"); }
+    const unsigned int nb = nblocks(ncol, 128);
+    hipLaunchKernelGGL(k_placement_probe, dim3(nb), dim3(128), 0, ctx->stream, rows, ncol, s);       // warm-up
+    hipError_t e = hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_placement_probe, dim3(nb), dim3(128), 0, ctx->stream, rows, ncol, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(ctx, PGW_ERR_HIP, "placement probe failed: %s", hipGetErrorString(e));
+    *gbps = ms > 0.f ? (double)rows * (double)ncol * 8.0 * (n_src + n_dst) * reps / ((double)ms * 1e6) : 0.0;
+    return PGW_OK;
+}
+
+extern "C" int pgw_ws_adopt(pgw_ctx *ctx, int slot, void *dptr, size_t bytes) {
+    NEED(ctx, slot >= 0 && slot < 8, "workspace slot out of range");
+    NEED(ctx, (dptr != nullptr) == (bytes > 0), "a buffer and its size, or neither (release the slot)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->ws[slot] && ctx->ws[slot] != dptr) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(ctx->ws[slot]));
+    }
+    ctx->ws[slot] = dptr; ctx->ws_bytes[slot] = bytes;
+    return PGW_OK;
+}
+
 extern "C" int pgw_byteswap(pgw_ctx *ctx, int elem_bytes, long long n, const void *src, void *dst) {
     NEED(ctx, elem_bytes == 4 || elem_bytes == 8, "elem_bytes must be 4 or 8");
     NEED(ctx, n >= 0 && (n == 0 || (src && dst)), "bad argument");

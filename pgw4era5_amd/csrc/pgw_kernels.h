@@ -2669,6 +2669,37 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_f64_f32(long long n2, long lon
     }
 }
 
+// Placement probe (pgw_placement_probe): the access pattern of the column kernels with no arithmetic - one thread per column,
+// blocks of 128 columns, `ns` read streams and `nd` write streams of (row, column) float64 arrays, two rows per step with the
+// next step's rows requested one step ahead, streaming loads and stores.  What it measures: the rate this set of arrays gets
+// WHERE hipMalloc put them - on an MI355X an array that is written while another one of the same stretch of physical memory
+// is read gets 5.0-5.4 TB/s, arrays of different stretches 5.7-6.2 (tools/micro/pair_matrix.hip).
+struct ProbeStreams { const double *src[4]; double *dst[4]; int ns, nd; };
+__global__ __launch_bounds__(128) void k_placement_probe(long long rows, long long ncol, ProbeStreams s) {
+    const long long c = (long long)blockIdx.x * 128 + threadIdx.x;
+    if (c >= ncol) return;
+    auto row_sum = [&](long long r) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < s.ns) a += __builtin_nontemporal_load(s.src[i] + r * ncol + c);
+        return a;
+    };
+    auto row_put = [&](long long r, double v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < s.nd) __builtin_nontemporal_store(v, s.dst[i] + r * ncol + c);
+    };
+    double a = row_sum(0), b = rows > 1 ? row_sum(1) : 0.0;
+    long long r = 0;
+    for (; r + 1 < rows; r += 2) {
+        double a2 = 0.0, b2 = 0.0;
+        if (r + 2 < rows) a2 = row_sum(r + 2);
+        if (r + 3 < rows) b2 = row_sum(r + 3);
+        row_put(r, a); row_put(r + 1, b);
+        a = a2; b = b2;
+    }
+    if (r < rows) row_put(r, a);
+}
+
 // Byte-order conversion of a field (NetCDF classic data are big-endian): every 4- or 8-byte element of `src` is
 // written byte-reversed to `dst` (in place allowed), 16 B per lane, grid-stride.  HBM-bound: 2 x n x W bytes.
 template <int W>

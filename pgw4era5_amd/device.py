@@ -262,6 +262,37 @@ class Context:
         a = DeviceArray(self, host.shape, dtype)
         return a.copy_from(host)
 
+    def placement_probe(self, src=(), dst=(), reps=3, rows=None):
+        """GB/s of the column kernels' access pattern, no arithmetic, over the read streams `src` and the write streams
+        `dst` (DeviceArrays of one size, <= 4 each; the dst arrays are OVERWRITTEN) - `pgw_placement_probe`: what this set
+        of arrays gets where hipMalloc put them.  `rows`: the leading rows to touch (default: all of them)."""
+        src, dst = list(src), list(dst)
+        if len(src) > 4 or len(dst) > 4 or not (src or dst):
+            raise ValueError('placement_probe takes 1 to 4 + 4 streams')
+        arrs = src + dst
+        nbytes = min(a.nbytes for a in arrs)
+        ncol = int(np.prod(arrs[0].shape[-2:], dtype=np.int64)) if arrs[0].ndim >= 2 else 1 << 20
+        n_rows = nbytes // (8 * ncol)
+        if rows is not None:
+            n_rows = min(n_rows, rows)
+        if n_rows < 1:
+            raise ValueError('arrays too small for a probe')
+        ps = (C.c_void_p * 4)(*[a.ptr for a in src])
+        pd = (C.c_void_p * 4)(*[a.ptr for a in dst])
+        g = C.c_double()
+        self._check(self.lib.pgw_placement_probe(self.handle, len(src), ps, len(dst), pd, n_rows, ncol, reps, C.byref(g)))
+        return g.value
+
+    def ws_adopt(self, slot, arr):
+        """Hand `arr` (a DeviceArray that owns its memory) to the library as workspace `slot` (`pgw_ws_adopt`; 0 = the
+        vapour-pressure field of the file path).  The library owns the memory from here on."""
+        if arr._owner is not arr or not arr.ptr:
+            raise ValueError('ws_adopt needs an array that owns its memory')
+        self._check(self.lib.pgw_ws_adopt(self.handle, slot, arr.ptr, arr.nbytes))
+        self._live -= arr.nbytes
+        arr._owner = None                  # no longer ours to free
+        return arr
+
     # ---- profiling -----------------------------------------------------------------------
     def profile(self, on=True):
         self._check(self.lib.pgw_profile_enable(self.handle, 1 if on else 0))

@@ -1608,3 +1608,53 @@ def test_device_exp_is_library_exp():
     ulp = np.abs(got[fin] - want[fin]) / np.spacing(want[fin])
     assert ulp.max() <= 1.0, ulp.max()
     assert np.isnan(got[np.isnan(x)]).all() and got[x == np.inf][0] == np.inf and got[x == -np.inf][0] == 0.0
+
+
+@pytest.mark.parametrize('rows,ncol', [(1, 5), (2, 130), (5, 300), (8, 128)])
+@pytest.mark.parametrize('ns,nd', [(1, 1), (4, 4), (0, 2), (3, 1)])
+def test_placement_probe_moves_the_bytes_it_reports(rows, ncol, ns, nd):
+    """pgw_placement_probe (the column kernels' access pattern with no arithmetic; measurement of where the arrays lie in
+    HBM, no counterpart in the reference): every element of every write stream is the sum of the read streams at its
+    place - odd row counts, a partial last block, no read streams - and the rate comes back positive."""
+    from pgw4era5_amd.device import default_context
+    ctx = default_context()
+    rng = np.random.default_rng(rows * 1000 + ncol)
+    src_h = [rng.normal(size=(1, rows, 1, ncol)) for _ in range(ns)]
+    src = [ctx.to_device(x) for x in src_h]
+    dst = [ctx.to_device(np.full((1, rows, 1, ncol), -7.0)) for _ in range(nd)]
+    g = ctx.placement_probe(src, dst, reps=2)
+    assert g > 0.0
+    want = np.zeros((1, rows, 1, ncol))
+    for x in src_h:                                 # the kernel's order of additions: stream 0 first, from 0.0
+        want = want + x
+    for d in dst:
+        np.testing.assert_array_equal(d.numpy(), want)
+    for x, d in zip(src_h, src):                    # read streams untouched
+        np.testing.assert_array_equal(d.numpy(), x)
+    with pytest.raises(ValueError):
+        ctx.placement_probe([dst[0]] * 5, dst)                                      # more than 4 read streams
+
+
+def test_an_adopted_workspace_changes_nothing_in_the_results():
+    """pgw_ws_adopt: the vapour-pressure workspace of the file path in a buffer the caller allocated (so that the host layer
+    can choose its place in HBM) - same bits as with the library's own; a buffer that is too small is replaced by the
+    library, not written past."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import default_context
+    c = _case(nlat=6, nlon=11, nlev=20, seed=5)
+    args = (c['delta_times'], c['plev'], c['target_dt'])
+    ctx = default_context()
+    want = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ignore_top_pressure_error=True)
+    for nbytes in (c['era']['T'].size * 8, c['era']['T'].size * 8 + 4096, 64):
+        ws = ctx.empty((nbytes // 8,), np.float64)
+        ctx.ws_adopt(0, ws)
+        assert ws._owner is None                    # the library's now
+        with pytest.raises(ValueError):
+            ctx.ws_adopt(0, ws)                     # not ours to hand over twice
+        got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ignore_top_pressure_error=True)
+        assert got['n_iter'] == want['n_iter']
+        for k in ('PS', 'T', 'QV', 'U', 'V'):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    ctx._check(ctx.lib.pgw_ws_adopt(ctx.handle, 0, None, 0))        # release
+    with pytest.raises(ValueError):
+        ctx._check(ctx.lib.pgw_ws_adopt(ctx.handle, 9, None, 0))
