@@ -832,3 +832,27 @@ def test_run_starmap_keeps_the_reference_call_forms():
     wrapped = [(dict(iter_arg=i, fixed_arg='x', func=P.test_IMP),) for i in range(3)]      # the njobs > 1 form of IterMP.run
     assert P.run_starmap(P.test_IMP, wrapped, njobs=1) == [0, 1, 2]
     assert P.starmap_helper(dict(func=P.test_IMP, iter_arg=7, fixed_arg=None)) == 7
+
+
+def test_smi_sampler_window_summary_without_a_card():
+    """tools/smi/sampler.py (bench.py's `device_state`): no helper library or no card -> `available` is False and every call
+    is a no-op; the window arithmetic (means, extremes, limiter residency from the accumulated counters) on fed samples."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('smi_sampler', os.path.join(ROOT, 'tools', 'smi', 'sampler.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    s = m.Sampler()
+    if not s.available:                              # this container: no GPU
+        assert s.summary() is None and s.start() is s and s.stop() is s and s.samples == []
+    base = {k: -1.0 for k in m.FIELDS}
+    def row(t, clk, lo, hi, w, acc, ppt):
+        r = dict(base, gfx_mhz=clk, gfx_mhz_min_xcd=lo, gfx_mhz_max_xcd=hi, power_w=w, acc_counter=acc, ppt_acc=ppt,
+                 socket_thm_acc=0.0, t_hotspot_c=50.0 + t)
+        return (float(t), r)
+    s.samples = [row(0, 2300, 2250, 2350, 400, 1000, 100), row(1, 2200, 2100, 2300, 1300, 2000, 700),
+                 row(2, 2100, 2000, 2200, 1390, 3000, 1500), row(3, 2400, 2400, 2400, 300, 4000, 1500)]
+    w = s.window(1.0, 2.0)
+    assert w['samples'] == 2 and w['gfx_mhz_mean'] == 2150.0 and w['gfx_mhz_min'] == 2000 and w['gfx_mhz_max'] == 2300
+    assert w['power_w_mean'] == 1345.0 and w['power_w_max'] == 1390 and w['ppt_residency'] == 0.8
+    assert w['socket_thm_residency'] == 0.0 and 'hbm_thm_residency' not in w and w['uclk_mhz'] is None
+    assert s.window(None, None)['samples'] == 4 and s.window(10, 11) is None
