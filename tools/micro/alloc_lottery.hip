@@ -53,7 +53,9 @@ __global__ __launch_bounds__(128) void k_write1(int nlev, int ncol, double *out)
 }
 
 int main(int argc, char **argv) {
-    const int nlev = 136, ncol = 721 * 1440, rounds = argc > 1 ? atoi(argv[1]) : 10, T = 20, arena_mode = argc > 2 ? atoi(argv[2]) : 0;
+    const int nlev = 136, ncol = 721 * 1440, rounds = argc > 1 ? atoi(argv[1]) : 10, T = 20, arena_mode_arg = argc > 2 ? atoi(argv[2]) : 0;
+    const bool contiguous = arena_mode_arg >= 3;          // 3: eight physically contiguous allocations per round; 4: one contiguous arena, spacings
+    const int arena_mode = arena_mode_arg == 3 ? 0 : (arena_mode_arg == 4 ? 2 : arena_mode_arg);
     const size_t n = (size_t)nlev * ncol;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const unsigned nb = (unsigned)((ncol + 127) / 128);
@@ -61,7 +63,8 @@ int main(int argc, char **argv) {
         // ONE arena for the life of the process; the eight arrays at base + k * spacing for a list of spacings, twice over
         const size_t MB = 1u << 20, field = (n * 8 + 2 * MB - 1) / (2 * MB) * (2 * MB);
         double *arena; const size_t bytes = 8 * (field + 600 * MB);
-        CK(hipMalloc(&arena, bytes)); CK(hipMemset(arena, 0, bytes));
+        if (contiguous) CK(hipExtMallocWithFlags((void **)&arena, bytes, hipDeviceMallocContiguous)); else CK(hipMalloc(&arena, bytes));
+        CK(hipMemset(arena, 0, bytes));
         const size_t extra[] = {0, 2 * MB, 4 * MB, 6 * MB, 8 * MB, 16 * MB, 32 * MB, 34 * MB, 64 * MB, 128 * MB, 130 * MB, 256 * MB, 258 * MB, 512 * MB,
                                 4096, 65536, 262144, 1 * MB, 3 * MB, 33 * MB + 4096, 128, 256, 512, 768, 1024, 1280, 2048, 2304, 4096 + 256, 8192 + 512, 16384 + 1024, 65536 + 256, 2 * MB + 256};
         for (int pass = 0; pass < 2; ++pass)
@@ -89,8 +92,10 @@ int main(int argc, char **argv) {
             for (int i = 0; i < NS; ++i) { s.in[i] = arena + (size_t)i * stride; s.out[i] = arena + (size_t)(NS + i) * stride; }
         } else {
             for (int i = 0; i < NS; ++i) {
-                double *p; CK(hipMalloc(&p, n * 8)); CK(hipMemset(p, 0, n * 8)); s.in[i] = p;
-                CK(hipMalloc(&s.out[i], n * 8));
+                double *p;
+                if (contiguous) { CK(hipExtMallocWithFlags((void **)&p, n * 8, hipDeviceMallocContiguous)); CK(hipExtMallocWithFlags((void **)&s.out[i], n * 8, hipDeviceMallocContiguous)); }
+                else { CK(hipMalloc(&p, n * 8)); CK(hipMalloc(&s.out[i], n * 8)); }
+                CK(hipMemset(p, 0, n * 8)); s.in[i] = p;
             }
         }
         printf("round %2d  dummy %9zu B  in0 %p out0 %p :", r, dummy_bytes, (void *)s.in[0], (void *)s.out[0]);
