@@ -518,6 +518,9 @@ def main(argv=None):
             bare = {'GBps': round(g, 1), 'frac_of_peak': round(g / HBM_PEAK_GBS, 4),
                     'what': 'k_placement_probe: 4 read + 4 write streams over the ERA inputs and the outputs of this run, '
                             'one thread per column, two levels per step, streaming loads / stores, no arithmetic'}
+            if era['T'].dtype.itemsize != 8:
+                bare['note'] = ('float32 inputs: the probe moves their BYTES (as half as many float64 rows) and writes as many rows '
+                                '- half the kernel\'s output rows; a looser yardstick than for float64 files')
             ctx.profile(not os.environ.get('PGW_BENCH_NOPROF'))
         except Exception as e:                      # noqa: BLE001 - a side measurement
             bare = {'error': '%s: %s' % (type(e).__name__, e)}
