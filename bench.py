@@ -465,6 +465,9 @@ def main(argv=None):
     _device._default = ctx                 # the functions.py mirror uses the process-wide context
     ncol = a.nlat * a.nlon
     N, S = a.nlev, len(case['plev'])
+    # level arrays over the card's memory regions (settings.placement = 'spread'; PGW_PLACEMENT=plain for the A/B): inputs,
+    # outputs and the vapour-pressure workspace of the file path, 9 arrays of one float64 field (+ 8 for the float32 leg's file)
+    placement = ctx.enable_placement(int(np.prod(case['era']['T'].shape)) * 8, 9 if a.no_extras else 17)
     deltas = s3.DeltaSet(ctx, case['deltas'], case['delta_times'], case['plev'], dtype)
     era = s3._upload_era(ctx, case['era'], dtype)
     coeffs = dict(ak=case['era']['ak'], bk=case['era']['bk'], soil1=case['era']['soil1'])
@@ -616,6 +619,7 @@ def main(argv=None):
             'overlap': overlap,
             'latency_mode': latency,
             'device': ctx.device_name(),
+            'placement': placement if placement is not None else {'mode': 'plain'},
             'setup_s': round(t_gen, 1),
         }
         if solo and not a.no_extras:

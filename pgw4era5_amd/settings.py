@@ -46,3 +46,9 @@ f32_file_mode = 'reference'
 # half the download and half the file written (file I/O is what bounds the end-to-end rate); PS and the pass count are the
 # reference's either way.
 f32_out_dtype = 'float64'
+
+# Placement of the level arrays (T, QV, U, V in and out, the vapour-pressure workspace) in the card's memory.  'spread': the
+# context draws them so that half lie in one stretch of physical memory and half in another (device.SpreadPool; the quad
+# kernel runs 12 % faster than with all of them in one stretch, which is what consecutive hipMallocs give; DESIGN.md section
+# 4).  'plain': plain allocations.  `PGW_PLACEMENT` overrides.  No influence on any result.
+placement = 'spread'

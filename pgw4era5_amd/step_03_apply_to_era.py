@@ -271,7 +271,13 @@ def _upload_era(ctx, era, dtype):
     out = {}
     for k in ('PS', 'FIS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE'):
         v = era[k]
-        out[k] = v if isinstance(v, DeviceArray) else ctx.to_device(np.ascontiguousarray(v, dtype=dtype), dtype)
+        if isinstance(v, DeviceArray):
+            out[k] = v
+        elif k in ('T', 'QV', 'U', 'V'):            # level fields: placed by the context (Context.level_array)
+            h = np.ascontiguousarray(v, dtype=dtype)
+            out[k] = ctx.level_array(h.shape, dtype).copy_from(h)
+        else:
+            out[k] = ctx.to_device(np.ascontiguousarray(v, dtype=dtype), dtype)
     return out
 
 
@@ -319,7 +325,7 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
 
     def buf(name, shape, dtype=dt):
         if name not in out or out[name].shape != tuple(shape) or out[name].dtype != dtype:
-            out[name] = ctx.empty(shape, dtype)
+            out[name] = ctx.level_array(shape, dtype) if name in ('T', 'QV', 'U', 'V') else ctx.empty(shape, dtype)
         return out[name]
 
     _, _, x_hi, x_new, _ = deltas.bracket(target_dt, 'ta')          # functions.py:224-283, the axis of the quad group
@@ -778,12 +784,14 @@ def _stage_upload(item):
     dtype = item['dtype']
     item['deltas'] = load_delta_set(ctx, item['delta_input_dir'], dtype)
     sets = _buffer_sets((item['era']['T'].shape, dtype.str))
+    with _BUFFER_LOCK:                              # once per process and grid: where the level arrays of the buffer sets lie
+        ctx.enable_placement(int(np.prod(item['era']['T'].shape, dtype=np.int64)) * 8, 8 * len(sets.all_inp) + 1)
     inp = _take(sets.inp)
     item['sets'], item['inp_set'] = sets, inp
     try:
         for k, v in item['era'].items():
             if k not in inp:
-                inp[k] = ctx.empty(v.shape, dtype)
+                inp[k] = ctx.level_array(v.shape, dtype) if k in ('T', 'QV', 'U', 'V') else ctx.empty(v.shape, dtype)
             inp[k].copy_from(v, sync=False, ctx=up)
         up.sync()                                           # the host copies may go, and the compute stream may read
     except BaseException:

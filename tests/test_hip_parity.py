@@ -1658,3 +1658,79 @@ def test_an_adopted_workspace_changes_nothing_in_the_results():
     ctx._check(ctx.lib.pgw_ws_adopt(ctx.handle, 0, None, 0))        # release
     with pytest.raises(ValueError):
         ctx._check(ctx.lib.pgw_ws_adopt(ctx.handle, 9, None, 0))
+
+
+def test_spread_pool_stock_alternation_and_fallbacks(monkeypatch):
+    """device.SpreadPool / Context.enable_placement / Context.level_array (placement of the level arrays over the card's
+    memory regions; no counterpart in the reference, no influence on results): arrays below the probe size are plain stock;
+    `take` alternates the two stock lists, serves smaller requests as views, refuses larger ones, and falls back to plain
+    memory when the stock is used up; `PGW_PLACEMENT=plain` turns the whole thing off."""
+    from pgw4era5_amd.device import Context, SpreadPool
+    ctx = Context(0)
+    try:
+        pool = SpreadPool(ctx, 4096, 5)
+        assert pool.info['classes'] == 1 and pool.info['kept'] == 5 and len(pool.stock[0]) == 5 and pool.stock[1] == []
+        pool.stock[1] = [pool.stock[0].pop(), pool.stock[0].pop()]                  # pretend two lie outside the reference's stretch
+        pool.info['classes'] = 2
+        got = [pool.take((8, 64), np.float64) for _ in range(5)]
+        assert [g.placement_class for g in got] == [0, 1, 0, 1, 0]
+        assert len(set(g.ptr for g in got)) == 5
+        extra = pool.take((2, 3), np.float32)                                       # stock used up: plain memory
+        assert extra.placement_class is None and extra.ptr not in [g.ptr for g in got]
+        with pytest.raises(ValueError):
+            pool.take((4097,), np.uint8 if False else np.float64)
+        x = np.arange(512, dtype=np.float64).reshape(8, 64)
+        np.testing.assert_array_equal(got[1].copy_from(x).numpy(), x)               # a view of a stock array is an ordinary array
+        assert pool.take_owner() is None
+        # the context-level switches
+        monkeypatch.setenv('PGW_PLACEMENT', 'plain')
+        assert ctx.enable_placement(1 << 16, 3) is None and getattr(ctx, '_spread', None) is None
+        monkeypatch.setenv('PGW_PLACEMENT', 'sideways')
+        with pytest.raises(ValueError):
+            ctx.enable_placement(1 << 16, 3)
+        monkeypatch.setenv('PGW_PLACEMENT', 'spread')
+        info = ctx.enable_placement(1 << 16, 3)
+        assert info['kept'] == 3 and ctx.enable_placement(1 << 16, 3) is info       # idempotent per size
+        a = ctx.level_array((1, 2, 64, 64), np.float64)                             # 64 KiB: the pool's size
+        b = ctx.level_array((1, 2, 64, 64), np.float32)                             # half of it: still a level field
+        c = ctx.level_array((16,), np.float64)                                      # a small array: plain
+        assert a.placement_class == 0 and b.placement_class == 0 and c.placement_class is None
+    finally:
+        ctx.close()
+
+
+def test_spread_pool_draw_with_probes_keeps_what_was_asked_for():
+    """The drawing loop with real probes (32 MiB arrays: above the probe size; a budget of 1 GiB, so no spacer fits): whatever
+    the card answers - one class or two - `count` distinct usable arrays come back and the rest is freed."""
+    from pgw4era5_amd.device import Context, SpreadPool
+    ctx = Context(0)
+    try:
+        live0 = ctx._live
+        pool = SpreadPool(ctx, 32 << 20, 6, budget_bytes=1 << 30)
+        assert pool.info['kept'] == 6 and pool.info['classes'] in (1, 2) and pool.info['drawn_GB'] <= 1.08
+        arrs = [pool.take((1, 4, 1024, 1024), np.float64) for _ in range(6)]
+        assert len(set(a.ptr for a in arrs)) == 6
+        assert ctx._live - live0 == 6 * (32 << 20)                                   # candidates beyond the stock were freed
+        for i, a in enumerate(arrs):
+            ctx._check(ctx.lib.pgw_memset(ctx.handle, a.ptr, i, a.nbytes))
+        for i, a in enumerate(arrs):
+            assert np.all(a.numpy().view(np.uint8) == i)
+    finally:
+        ctx.close()
+
+
+def test_whole_file_results_do_not_depend_on_placement():
+    """The same file through the process-wide context before and after `enable_placement` (level arrays and the library's
+    vapour-pressure workspace from the pool): identical bits."""
+    from pgw4era5_amd import step_03_apply_to_era as s3
+    from pgw4era5_amd.device import default_context
+    c = _case(nlat=6, nlon=11, nlev=20, seed=8)
+    args = (c['delta_times'], c['plev'], c['target_dt'])
+    want = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ignore_top_pressure_error=True)
+    ctx = default_context()
+    info = ctx.enable_placement(c['era']['T'].size * 8, 9)
+    assert info is None or info['kept'] == 9
+    got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ignore_top_pressure_error=True)
+    assert got['n_iter'] == want['n_iter']
+    for k in ('PS', 'T', 'QV', 'U', 'V'):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
