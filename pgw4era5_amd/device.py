@@ -430,7 +430,7 @@ class Context:
         if cur is not None and cur.nbytes >= field_bytes:
             return cur.info
         pool = SpreadPool(self, field_bytes, count, budget_bytes)
-        ws = pool.take_owner(0)
+        ws = pool.take_owner(0)                     # (its class: 0 or 1 measured the same)
         if ws is not None:
             self.ws_adopt(0, ws)
         self._spread = pool

@@ -1729,7 +1729,7 @@ def test_whole_file_results_do_not_depend_on_placement():
     want = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ignore_top_pressure_error=True)
     ctx = default_context()
     info = ctx.enable_placement(c['era']['T'].size * 8, 9)
-    assert info is None or info['kept'] == 9
+    assert info is None or info['kept'] >= 9        # >: a driver test before this one has set the process-wide pool up already
     got = s3.pgw_for_era5_arrays(c['era'], c['deltas'], *args, ignore_top_pressure_error=True)
     assert got['n_iter'] == want['n_iter']
     for k in ('PS', 'T', 'QV', 'U', 'V'):
