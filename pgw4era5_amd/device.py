@@ -165,11 +165,20 @@ class SpreadPool:
         self.ctx, self.nbytes, self.count = ctx, int(nbytes), int(count)
         free, _total = ctx.mem_info()
         if budget_bytes is None:
-            budget_bytes = min(int(0.45 * free), 200 << 30)    # under half: two ranks rehearsing on one card both fit
+            # under half of what is free, and a rank that shares its card (more local ranks than devices: a rehearsal) takes
+            # its share of that only - the draw must never starve a neighbour's ordinary allocations
+            n_dev = C.c_int(0)
+            ctx.lib.pgw_device_count(C.byref(n_dev))
+            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('PGW_LOCAL_WORLD', '1')) or 1)
+            share = max(1, -(-local_world // max(n_dev.value, 1)))
+            budget_bytes = min(int(0.45 * free) // share, 200 << 30)
         self.stock = [[], []]                       # class 0 = the reference's stretch, class 1 = outside it
         self._next = 0
         self.info = {'classes': 1, 'drawn_GB': 0.0, 'kept': 0, 'copy_GBps_inside': None, 'copy_GBps_outside': None}
+        import time
+        t0 = time.perf_counter()
         self._draw(budget_bytes)
+        self.info['seconds'] = round(time.perf_counter() - t0, 2)
 
     def _probe(self, a, b):
         # a float64 view of both: rows x 1 Mi columns (the probe needs whole rows)

@@ -31,10 +31,12 @@ def main():
     S.f32_file_mode = a.f32_mode
     ctx = default_context()
     case = synthetic.make_case(nlat=a.nlat, nlon=a.nlon, nlev=a.nlev, seed=1, dtype=dtype)
+    placement = ctx.enable_placement(int(np.prod(case['era']['T'].shape)) * 8, 13)      # inputs 4, outputs 4 per leg, workspace
     deltas = s3.DeltaSet(ctx, case['deltas'], case['delta_times'], case['plev'], dtype)
     era = s3._upload_era(ctx, case['era'], dtype)
     coeffs = dict(ak=case['era']['ak'], bk=case['era']['bk'], soil1=case['era']['soil1'])
     out = {k: bench.mode_leg(ctx, era, coeffs, deltas, case, a, which) for k, which in (('local_p_ref', 'local'), ('i_reinterp', 'reinterp'))}
+    out['placement'] = placement if placement is not None else {'mode': 'plain'}
     print(json.dumps(out))
 
 
