@@ -311,7 +311,14 @@ extern "C" int pgw_device_name(pgw_ctx *ctx, char *buf, size_t len) {
 // ------------------------------------------------------------------ memory
 extern "C" int pgw_malloc(pgw_ctx *ctx, size_t bytes, void **dptr) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    const hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        // an allocation that does not fit is an answer, not a fault of the context: clear HIP's sticky last error so that the
+        // hipGetLastError() after the next kernel launch does not report it (the placement draw probes how much fits)
+        (void)hipGetLastError();
+        *dptr = nullptr;
+        return fail(ctx, PGW_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
     return PGW_OK;
 }
 extern "C" int pgw_free(pgw_ctx *ctx, void *dptr) {

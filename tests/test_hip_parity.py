@@ -1734,3 +1734,22 @@ def test_whole_file_results_do_not_depend_on_placement():
     assert got['n_iter'] == want['n_iter']
     for k in ('PS', 'T', 'QV', 'U', 'V'):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
+def test_an_allocation_that_does_not_fit_leaves_the_context_usable():
+    """pgw_malloc of more than the card has: PGWHipError, and no sticky HIP error left behind - the next kernel launch on the
+    context succeeds (the placement draw relies on this when its budget meets a busy card)."""
+    from pgw4era5_amd import _lib
+    from pgw4era5_amd.device import Context
+    ctx = Context(0)
+    try:
+        _free, total = ctx.mem_info()
+        with pytest.raises(_lib.PGWHipError):
+            ctx.empty((total // 8 + (1 << 28),), np.float64)
+        x = np.arange(1024, dtype=np.float64)
+        d = ctx.to_device(x)
+        out = ctx.empty((1024,), np.float64)
+        ctx._check(ctx.lib.pgw_byteswap(ctx.handle, 8, 1024, d.ptr, out.ptr))
+        np.testing.assert_array_equal(out.numpy().view(np.uint8), x.byteswap().view(np.uint8))
+    finally:
+        ctx.close()
