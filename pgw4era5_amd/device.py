@@ -148,6 +148,25 @@ class DeviceArray:
         return self.numpy()
 
 
+class _PooledArray(DeviceArray):
+    """A stock array of a SpreadPool: when the last view of it is gone it goes back into the pool's stock (same memory, same
+    class) instead of back to hipMalloc - so that a long run keeps its placement.  `Context.ws_adopt` and `free()` take it
+    out of this cycle."""
+
+    __slots__ = ('_pool', '_cls')
+
+    def __del__(self):
+        try:
+            pool = self._pool
+            if self._owner is self and self.ptr and self.ctx.handle and pool is not None and not pool.closed:
+                pool._recycle(self.ptr, self.nbytes, self._cls)
+                self.ptr = None                      # the memory lives on in a new stock object
+                return
+        except Exception:
+            pass
+        DeviceArray.__del__(self)
+
+
 class SpreadPool:
     """Level arrays of one size placed over the card's memory regions (no counterpart in the reference: numpy arrays live
     wherever malloc put them).  On an MI355X the arrays a column kernel reads and writes at the same time run 12 % faster
@@ -155,8 +174,8 @@ class SpreadPool:
     level arrays in one stretch, 1.87-1.89 ms with both the inputs and the outputs spread over two or three) - and
     consecutive hipMallocs come from one stretch for the first 60-90 GB.  The pool therefore DRAWS: a reference array, then
     candidates (with spacers between them) until `count` arrays are in stock, half of them in the reference's stretch and
-    half outside it - told apart by `Context.placement_probe` of a copy reference -> candidate, which is 5-7 % slower inside a
-    stretch - and frees the rest.  `take()` hands the stock out alternating between the classes.  When the draw finds no
+    half outside it - told apart by `Context.placement_probe` of two write streams, reference + candidate: 5.45 TB/s when
+    both lie in one stretch, 6.75 when they do not - and frees the rest.  `take()` hands the stock out alternating between the classes.  When the draw finds no
     second class within its budget (a small or busy card) the stock is plain arrays and `info['classes']` says 1."""
 
     SPACER = 8 << 30
@@ -174,8 +193,9 @@ class SpreadPool:
             share = max(1, -(-local_world // max(n_dev.value, 1)))
             budget_bytes = int(0.85 * free) // share if share == 1 else int(0.45 * free) // share
         self.stock = [[], []]                       # class 0 = the reference's stretch, class 1 = outside it
+        self.closed = False
         self._next = 0
-        self.info = {'classes': 1, 'drawn_GB': 0.0, 'kept': 0, 'copy_GBps_inside': None, 'copy_GBps_outside': None}
+        self.info = {'classes': 1, 'drawn_GB': 0.0, 'kept': 0, 'probe_GBps_inside': None, 'probe_GBps_outside': None}
         import time
         t0 = time.perf_counter()
         self._draw(budget_bytes)
@@ -189,7 +209,7 @@ class SpreadPool:
             return None
         va = DeviceArray(self.ctx, (1, rows, 1, ncol), np.float64, ptr=a.ptr, owner=a)
         vb = DeviceArray(self.ctx, (1, rows, 1, ncol), np.float64, ptr=b.ptr, owner=b)
-        return self.ctx.placement_probe([va], [vb], reps=3)
+        return self.ctx.placement_probe([], [va, vb], reps=3)       # two write streams: 5.45 TB/s inside one stretch, 6.75 across two
 
     def _draw(self, budget):
         ctx, n = self.ctx, self.nbytes
@@ -231,8 +251,8 @@ class SpreadPool:
                 r = self._probe(ref, a)
                 rates.append(r)
                 lo, hi = min(rates), max(rates)
-                # two populations 5-7 % apart; until both have been seen everything counts as the reference's stretch
-                split = hi > 1.035 * lo
+                # two populations 20-25 % apart; until both have been seen everything counts as the reference's stretch
+                split = hi > 1.10 * lo
                 cls = 1 if (split and r > 0.5 * (lo + hi)) else 0
                 cands.append((a, cls))
                 if split:                           # re-label what was seen before the second population showed up
@@ -257,10 +277,32 @@ class SpreadPool:
             lo, hi = min(rates), max(rates)
             mid = 0.5 * (lo + hi)
             ins, outs = [r for r in rates if r <= mid], [r for r in rates if r > mid]
-            self.info.update(classes=2, copy_GBps_inside=round(sum(ins) / len(ins)) if ins else None,
-                             copy_GBps_outside=round(sum(outs) / len(outs)) if outs else None)
+            self.info.update(classes=2, probe_GBps_inside=round(sum(ins) / len(ins)) if ins else None,
+                             probe_GBps_outside=round(sum(outs) / len(outs)) if outs else None)
+        for c in (0, 1):                            # stock objects that come back when their last view is dropped
+            self.stock[c] = [self._pooled(a, c) for a in self.stock[c]]
         self.info.update(drawn_GB=round(spent / 1e9, 1), kept=len(self.stock[0]) + len(self.stock[1]),
                          kept_per_class=[len(self.stock[0]), len(self.stock[1])])
+
+    def _pooled(self, a, cls):
+        """the memory of the plain array `a` as a _PooledArray of class `cls`"""
+        p = _PooledArray(self.ctx, a.shape, a.dtype, ptr=a.ptr)
+        p._owner, p._pool, p._cls = p, self, cls
+        a._owner, a.ptr = None, None                # `a` no longer owns anything (its bytes stay counted in ctx._live)
+        return p
+
+    def _recycle(self, ptr, nbytes, cls):
+        p = _PooledArray(self.ctx, (nbytes // 8,), np.float64, ptr=ptr)
+        p._owner, p._pool, p._cls = p, self, cls
+        self.stock[cls].append(p)
+
+    def close(self):
+        """free the stock; arrays still in use are freed (not recycled) when their last view goes"""
+        self.closed = True
+        for c in (0, 1):
+            for a in self.stock[c]:
+                a.free()
+            self.stock[c] = []
 
     def take(self, shape, dtype, cls=None):
         """One array of the stock as a DeviceArray of `shape` / `dtype` (at most `nbytes`), classes alternating from call
@@ -269,6 +311,9 @@ class SpreadPool:
         if need > self.nbytes:
             raise ValueError('SpreadPool of %d-byte arrays asked for %d bytes' % (self.nbytes, need))
         order = [self._next % 2, (self._next + 1) % 2] if cls is None else [cls % 2, (cls + 1) % 2]
+        if not (self.stock[0] or self.stock[1]):
+            import gc
+            gc.collect()                            # an owning array refers to itself: dropped ones come back with the collector
         for c in order:
             if self.stock[c]:
                 if cls is None:
@@ -359,6 +404,9 @@ class Context:
         for c in self._side.values():
             c.close()
         self._side = {}
+        if getattr(self, '_spread', None) is not None:
+            self._spread.close()
+            self._spread = None
         if self.handle:
             self.lib.pgw_ctx_destroy(self.handle)
             self.handle = None

@@ -1671,6 +1671,8 @@ def test_spread_pool_stock_alternation_and_fallbacks(monkeypatch):
         pool = SpreadPool(ctx, 4096, 5)
         assert pool.info['classes'] == 1 and pool.info['kept'] == 5 and len(pool.stock[0]) == 5 and pool.stock[1] == []
         pool.stock[1] = [pool.stock[0].pop(), pool.stock[0].pop()]                  # pretend two lie outside the reference's stretch
+        for a in pool.stock[1]:
+            a._cls = 1
         pool.info['classes'] = 2
         got = [pool.take((8, 64), np.float64) for _ in range(5)]
         assert [g.placement_class for g in got] == [0, 1, 0, 1, 0]
@@ -1682,6 +1684,13 @@ def test_spread_pool_stock_alternation_and_fallbacks(monkeypatch):
         x = np.arange(512, dtype=np.float64).reshape(8, 64)
         np.testing.assert_array_equal(got[1].copy_from(x).numpy(), x)               # a view of a stock array is an ordinary array
         assert pool.take_owner() is None
+        ptr1 = got[1].ptr
+        del got[1]                                                                  # the last view gone: back into the stock, same class
+        import gc
+        gc.collect()                                                                # (an owning array refers to itself)
+        assert [a.ptr for a in pool.stock[1]] == [ptr1] and pool.stock[0] == []
+        again = pool.take((8, 64), np.float64, cls=1)
+        assert again.ptr == ptr1 and again.placement_class == 1
         # the context-level switches
         monkeypatch.setenv('PGW_PLACEMENT', 'plain')
         assert ctx.enable_placement(1 << 16, 3) is None and getattr(ctx, '_spread', None) is None

@@ -13,6 +13,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ctx = default_context()
 case = synthetic.make_case(nlat=721, nlon=1440, nlev=137, seed=1, dtype=dtype)
 coeffs = dict(ak=case['era']['ak'], bk=case['era']['bk'], soil1=case['era']['soil1'])
+print('placement', ctx.enable_placement(138 * 721 * 1440 * 8, 12))           # PGW_PLACEMENT=plain for the A/B
 era = s3._upload_era(ctx, case['era'], dtype)
 class A: pass
 bench.microbench(ctx, era, coeffs, A(), np, reps=30)       # clocks up (the card idles at 150 MHz)
