@@ -93,7 +93,10 @@ if nc >= 2:
     for rep in range(2):
         run('all in class 0', [0] * 4, [0] * 4, 0)
         run('two classes alternating (what SpreadPool does)', [0, 1, 0, 1], [1, 0, 1, 0], 0)
-        if nc >= 3:
+        run('in 0 1 0 1, out 0 1 0 1, ws 0 (T_pgw and e together)', [0, 1, 0, 1], [0, 1, 0, 1], 0)
+        run('in 0 0 1 1 (T, QV together), out 0 1 0 1, ws 0', [0, 0, 1, 1], [0, 1, 0, 1], 0)
+        run('in 0 0 1 1, out 0 0 1 1, ws 0 (T_pgw, QV_out and e together)', [0, 0, 1, 1], [0, 0, 1, 1], 0)
+        if nc >= 3 and os.environ.get('THREE'):
             run('three classes round robin', [0, 1, 2, 0], [1, 2, 0, 1], 2)
         if nc >= 4:
             run('four classes round robin', [0, 1, 2, 3], [1, 2, 3, 0], 2)
