@@ -476,7 +476,7 @@ class Context:
     def enable_placement(self, field_bytes, count, budget_bytes=None):
         """Place the level arrays of this context's files over the card's memory regions (`SpreadPool`; settings.placement =
         'spread', the default; `PGW_PLACEMENT=plain` or settings.placement = 'plain' turn it off): draws `count` arrays of
-        `field_bytes`, hands the first one to the library as its vapour-pressure workspace and serves `level_array()` from
+        `field_bytes`, hands one of class 1 to the library as its vapour-pressure workspace and serves `level_array()` from
         the rest.  Returns the pool's `info` (None when placement is off).  Idempotent per size."""
         from . import settings as S
         mode = os.environ.get('PGW_PLACEMENT', getattr(S, 'placement', 'spread'))
@@ -488,7 +488,7 @@ class Context:
         if cur is not None and cur.nbytes >= field_bytes:
             return cur.info
         pool = SpreadPool(self, field_bytes, count, budget_bytes)
-        ws = pool.take_owner(0)                     # (its class: 0 or 1 measured the same)
+        ws = pool.take_owner(1)                     # class 1: with T, U (0) and V (1) the quad kernel's writes are two and two
         if ws is not None:
             self.ws_adopt(0, ws)
         self._spread = pool

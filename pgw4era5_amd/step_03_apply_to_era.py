@@ -267,6 +267,13 @@ class DeltaSet:
         self.dev, self._cache, self.ts_clim = {}, {}, None
 
 
+# Placement classes of the level arrays (device.SpreadPool; only their balance matters): the write streams
+# of the quad kernel - T, e (the library's workspace: class 1, Context.enable_placement), U, V on the hybrid levels - two and two;
+# the final kernel reads e (1) and writes QV (0); the inputs two and two.
+LEVEL_CLASS_IN = {'T': 0, 'QV': 1, 'U': 0, 'V': 1}
+LEVEL_CLASS_OUT = {'T': 0, 'QV': 0, 'U': 0, 'V': 1}
+
+
 def _upload_era(ctx, era, dtype):
     out = {}
     for k in ('PS', 'FIS', 'T', 'QV', 'U', 'V', 'T_SKIN', 'T_SO', 'FR_LAND', 'FR_SEA_ICE'):
@@ -275,7 +282,7 @@ def _upload_era(ctx, era, dtype):
             out[k] = v
         elif k in ('T', 'QV', 'U', 'V'):            # level fields: placed by the context (Context.level_array)
             h = np.ascontiguousarray(v, dtype=dtype)
-            out[k] = ctx.level_array(h.shape, dtype).copy_from(h)
+            out[k] = ctx.level_array(h.shape, dtype, LEVEL_CLASS_IN[k]).copy_from(h)
         else:
             out[k] = ctx.to_device(np.ascontiguousarray(v, dtype=dtype), dtype)
     return out
@@ -325,7 +332,7 @@ def process_file_device(ctx, era, coeffs, deltas, target_dt, ignore_top_pressure
 
     def buf(name, shape, dtype=dt):
         if name not in out or out[name].shape != tuple(shape) or out[name].dtype != dtype:
-            out[name] = ctx.level_array(shape, dtype) if name in ('T', 'QV', 'U', 'V') else ctx.empty(shape, dtype)
+            out[name] = ctx.level_array(shape, dtype, LEVEL_CLASS_OUT[name]) if name in LEVEL_CLASS_OUT else ctx.empty(shape, dtype)
         return out[name]
 
     _, _, x_hi, x_new, _ = deltas.bracket(target_dt, 'ta')          # functions.py:224-283, the axis of the quad group
@@ -791,7 +798,7 @@ def _stage_upload(item):
     try:
         for k, v in item['era'].items():
             if k not in inp:
-                inp[k] = ctx.level_array(v.shape, dtype) if k in ('T', 'QV', 'U', 'V') else ctx.empty(v.shape, dtype)
+                inp[k] = ctx.level_array(v.shape, dtype, LEVEL_CLASS_IN[k]) if k in LEVEL_CLASS_IN else ctx.empty(v.shape, dtype)
             inp[k].copy_from(v, sync=False, ctx=up)
         up.sync()                                           # the host copies may go, and the compute stream may read
     except BaseException:
