@@ -174,8 +174,9 @@ class SpreadPool:
     level arrays in one stretch, 1.87-1.89 ms with both the inputs and the outputs spread over two or three) - and
     consecutive hipMallocs come from one stretch for the first 60-90 GB.  The pool therefore DRAWS: a reference array, then
     candidates (with spacers between them) until `count` arrays are in stock, half of them in the reference's stretch and
-    half outside it - told apart by `Context.placement_probe` of two write streams, reference + candidate: 5.45 TB/s when
-    both lie in one stretch, 6.75 when they do not - and frees the rest.  `take()` hands the stock out alternating between the classes.  When the draw finds no
+    half outside it - told apart by `Context.placement_probe` of two write streams, reference + candidate: 5.0-5.45 TB/s when
+    both lie in one stretch, 6.6-6.9 when they do not - and frees the rest.  `take()` hands the stock out by class (or
+    alternating); an array whose last view is dropped comes back into the stock (`_PooledArray`).  When the draw finds no
     second class within its budget (a small or busy card) the stock is plain arrays and `info['classes']` says 1."""
 
     SPACER = 8 << 30
@@ -209,7 +210,7 @@ class SpreadPool:
             return None
         va = DeviceArray(self.ctx, (1, rows, 1, ncol), np.float64, ptr=a.ptr, owner=a)
         vb = DeviceArray(self.ctx, (1, rows, 1, ncol), np.float64, ptr=b.ptr, owner=b)
-        return self.ctx.placement_probe([], [va, vb], reps=3)       # two write streams: 5.45 TB/s inside one stretch, 6.75 across two
+        return self.ctx.placement_probe([], [va, vb], reps=3)       # two write streams: ~5 TB/s inside one stretch, ~6.7 across two
 
     def _draw(self, budget):
         ctx, n = self.ctx, self.nbytes
@@ -229,7 +230,7 @@ class SpreadPool:
         ref = alloc(n)
         if ref is None:
             raise _lib.PGWHipError('SpreadPool: no memory for the first array')
-        cands = []                                  # (array, copy rate from the reference)
+        cands = []                                  # (array, class); rates[i] = probe rate of cands[i] with the reference
         rates = []
         if n >= 2 * 8 * (1 << 20):                  # arrays of at least two probe rows: worth placing
             spacer_next = False
