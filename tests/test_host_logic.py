@@ -856,3 +856,79 @@ def test_smi_sampler_window_summary_without_a_card():
     assert w['power_w_mean'] == 1345.0 and w['power_w_max'] == 1390 and w['ppt_residency'] == 0.8
     assert w['socket_thm_residency'] == 0.0 and 'hbm_thm_residency' not in w and w['uclk_mhz'] is None
     assert s.window(None, None)['samples'] == 4 and s.window(10, 11) is None
+
+
+def test_spread_pool_draw_logic_with_a_simulated_card():
+    """device.SpreadPool without a GPU: a stand-in context whose memory is handed out in allocation order and whose two-write
+    probe answers 5000 GB/s for two arrays of one 90 GB stretch and 6600 across stretches (what the MI355X does, DESIGN.md
+    section 4).  The draw strides through the first stretch with spacers, keeps half of the stock inside and half outside,
+    frees everything else, stays within its budget (one class when the budget ends inside the first stretch), and dropped
+    arrays come back into the stock."""
+    import gc
+    from pgw4era5_amd import device as D
+
+    class Lib:
+        def __init__(self):
+            self.freed = []
+
+        def pgw_free(self, h, p):
+            self.freed.append(p)
+            return 0
+
+        def pgw_device_count(self, ref):
+            ref._obj.value = 1
+            return 0
+
+    class Ctx:
+        STRETCH = 90e9
+
+        def __init__(self):
+            self.handle, self._live, self.lib, self.cursor, self.alive = 1, 0, Lib(), 4096, {}
+
+        def mem_info(self):
+            return int(300e9), int(300e9)
+
+        def empty(self, shape, dtype):
+            n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            a = D.DeviceArray(self, shape, dtype, ptr=self.cursor)
+            a._owner = a
+            self.alive[self.cursor] = n
+            self.cursor += n
+            self._live += n
+            return a
+
+        def region(self, ptr):
+            return int(ptr // self.STRETCH)
+
+        def placement_probe(self, src, dst, reps=3, rows=None):
+            a, b = dst
+            return 5000.0 if self.region(a.ptr) == self.region(b.ptr) else 6600.0
+
+    field = 137 * 721 * 1440 * 8
+    ctx = Ctx()
+    pool = D.SpreadPool(ctx, field, 9)
+    assert pool.info['classes'] == 2 and pool.info['kept_per_class'] == [5, 4] and pool.info['drawn_GB'] > 90
+    assert pool.info['probe_GBps_inside'] == 5000 and pool.info['probe_GBps_outside'] == 6600
+    assert all(ctx.region(a.ptr) == 0 for a in pool.stock[0]) and all(ctx.region(a.ptr) >= 1 for a in pool.stock[1])
+    kept = {a.ptr for a in pool.stock[0] + pool.stock[1]}
+    assert set(ctx.alive) - set(ctx.lib.freed) == kept              # spacers and surplus candidates all went back
+    spacers = [p for p in ctx.lib.freed if ctx.alive[p] == D.SpreadPool.SPACER]
+    assert 8 <= len(spacers) <= 12                                    # ~ (90 GB - 5 arrays) / (8 GiB + one array)
+    views = [pool.take((1, 137, 721, 1440), np.float64, cls=c) for c in (0, 1, 0, 1)]
+    assert [v.placement_class for v in views] == [0, 1, 0, 1] and len(pool.stock[0]) == 3 and len(pool.stock[1]) == 2
+    p1 = views[1].ptr
+    del views[1]
+    gc.collect()
+    assert [a.ptr for a in pool.stock[1]][-1] == p1 and len(pool.stock[1]) == 3      # dropped -> back, same class
+    half = pool.take((1, 137, 721, 1440), np.float32)                # a float32 field of a float64 pool: a view of a stock array
+    assert half.nbytes == field // 2 and half.placement_class in (0, 1)
+    pool.close()
+    assert pool.stock == [[], []]
+    # a budget that ends inside the first stretch: plain stock, one class
+    ctx2 = Ctx()
+    pool2 = D.SpreadPool(ctx2, field, 9, budget_bytes=int(40e9))
+    assert pool2.info['classes'] == 1 and pool2.info['kept'] == 9 and pool2.info['drawn_GB'] <= 40.0 + 9 * field / 1e9
+    assert len(pool2.stock[0]) == 9 and pool2.stock[1] == []
+    # small arrays are not worth a draw
+    pool3 = D.SpreadPool(Ctx(), 4096, 3)
+    assert pool3.info['classes'] == 1 and pool3.info['kept'] == 3 and pool3.info['drawn_GB'] == 0.0
