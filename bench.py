@@ -406,11 +406,12 @@ def main(argv=None):
 
     # host placement of this rank: its GPU's NUMA node, a CPU set disjoint from the other ranks' (before any pinned
     # allocation and before the stage threads exist)
-    from pgw4era5_amd.parallel import bind_rank_to_numa
+    from pgw4era5_amd.parallel import bind_rank_to_numa, card_share
     try:
         affinity = bind_rank_to_numa(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
     except Exception as e:                  # noqa: BLE001 - placement is an optimisation, never a reason to lose the line
         affinity = {'bound': False, 'note': '%s: %s' % (type(e).__name__, e)}
+    affinity['card_share'] = card_share(dist, local)       # ranks on this rank's card (PGW_CARD_SHARE for the placement draw)
 
     def reduce(x, op):
         """float all-reduce over the ranks (RCCL on device memory, gloo on host memory)"""

@@ -188,10 +188,13 @@ class SpreadPool:
             # most of what is free (the reference's stretch has been seen to span 60 ... 140 GB; everything drawn beyond the
             # stock goes back within the second), but a rank that shares its card (more local ranks than devices: a
             # rehearsal) takes its share of under half only - the draw must never starve a neighbour's ordinary allocations
-            n_dev = C.c_int(0)
-            ctx.lib.pgw_device_count(C.byref(n_dev))
-            local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('PGW_LOCAL_WORLD', '1')) or 1)
-            share = max(1, -(-local_world // max(n_dev.value, 1)))
+            if os.environ.get('PGW_CARD_SHARE'):        # parallel.card_share: the ranks' PCI addresses, gathered
+                share = max(1, int(os.environ['PGW_CARD_SHARE']))
+            else:                                       # no process group: more local ranks than visible devices = sharing
+                n_dev = C.c_int(0)
+                ctx.lib.pgw_device_count(C.byref(n_dev))
+                local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('PGW_LOCAL_WORLD', '1')) or 1)
+                share = max(1, -(-local_world // max(n_dev.value, 1)))
             budget_bytes = int(0.85 * free) // share if share == 1 else int(0.45 * free) // share
         self.stock = [[], []]                       # class 0 = the reference's stretch, class 1 = outside it
         self.closed = False

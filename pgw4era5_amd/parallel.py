@@ -138,6 +138,33 @@ def rank_cpu_set(local_rank, local_world, allowed, gpu_nodes=None, cpus_of_node=
     return set(sets[local_rank])
 
 
+def card_share(dist=None, local_rank=None):
+    """How many ranks of this job use the SAME card as this one: every rank's (host, PCI address of its device) gathered over
+    `torch.distributed` when a process group is up - right whether the ranks see all devices or one each
+    (`HIP_VISIBLE_DEVICES` per rank) - else 1.  Exported as PGW_CARD_SHARE for `device.SpreadPool`, whose draw takes most of
+    the card's free memory only when nobody shares it."""
+    import ctypes as C
+    import socket
+    share = 1
+    try:
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import _lib
+            lib = _lib.load()
+            have = C.c_int(0)
+            lib.pgw_device_count(C.byref(have))
+            d = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else int(local_rank)
+            buf = C.create_string_buffer(32)
+            addr = buf.value.decode() if (have.value > 0 and lib.pgw_device_pci_bus_id(d % have.value, buf, 32) == 0) else ''
+            mine = (socket.gethostname(), addr)
+            everyone = [None] * dist.get_world_size()
+            dist.all_gather_object(everyone, mine)
+            share = max(1, sum(1 for x in everyone if x == mine)) if addr else 1
+    except Exception:                          # noqa: BLE001 - an optimisation's input: fall back to the environment's answer
+        share = 1
+    os.environ['PGW_CARD_SHARE'] = str(share)
+    return share
+
+
 def bind_rank_to_numa(local_rank=None, local_world=None):
     """Bind this process (and the threads it starts from now on: stage threads, NetCDF reader / writer pools) to its
     rank's CPU set, before pinned host buffers are allocated so that they are placed on that node.  PGW_NUMA_BIND=0
@@ -334,6 +361,7 @@ class IterMP:
         mine = []
         try:
             bind_rank_to_numa()                          # LOCAL_RANK / LOCAL_WORLD_SIZE of torch.distributed.run
+            card_share(dist)                             # PGW_CARD_SHARE for the placement draw (device.SpreadPool)
             mine = run_shard(func, tasks, shard_indices(len(tasks), rank, world))
         except Exception as e:            # noqa: BLE001 - every rank must reach the gather
             err = '%s: %s' % (type(e).__name__, e)

@@ -455,7 +455,7 @@ import os, sys, json
 sys.path.insert(0, %r)
 from pgw4era5_amd.parallel import IterMP
 def task(x, k):
-    return [x * k, int(os.environ['RANK'])]
+    return [x * k, int(os.environ['RANK']), os.environ.get('PGW_CARD_SHARE')]
 imp = IterMP(njobs=2, backend='gloo')
 imp.run(task, dict(k=5), [dict(x=i) for i in range(7)])
 if int(os.environ['RANK']) == 0:
@@ -476,6 +476,8 @@ def test_itermp_world_size_2_gloo(tmp_path):
     out = json.loads(line[7:])
     assert [o[0] for o in out] == [0, 5, 10, 15, 20, 25, 30]
     assert [o[1] for o in out] == [0, 1, 0, 1, 0, 1, 0]
+    # parallel.card_share ran on every rank before its shard (no device here: nobody shares a card)
+    assert [o[2] for o in out] == ['1'] * 7
 
 
 def _dying_task(x):
