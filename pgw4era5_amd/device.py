@@ -491,10 +491,15 @@ class Context:
         cur = getattr(self, '_spread', None)
         if cur is not None and cur.nbytes >= field_bytes:
             return cur.info
-        pool = SpreadPool(self, field_bytes, count, budget_bytes)
-        ws = pool.take_owner(1)                     # class 1: with T, U (0) and V (1) the quad kernel's writes are two and two
-        if ws is not None:
-            self.ws_adopt(0, ws)
+        try:
+            pool = SpreadPool(self, field_bytes, count, budget_bytes)
+            ws = pool.take_owner(1)                 # class 1: with T, U (0) and V (1) the quad kernel's writes are two and two
+            if ws is not None:
+                self.ws_adopt(0, ws)
+        except Exception as e:                      # noqa: BLE001 - placement is an optimisation: never a reason to lose a run
+            import sys
+            sys.stderr.write('pgw4era5_amd: placement of the level arrays skipped (%s: %s)\n' % (type(e).__name__, e))
+            return {'classes': 1, 'error': '%s: %s' % (type(e).__name__, e)}
         self._spread = pool
         return pool.info
 
